@@ -1,0 +1,217 @@
+"""ctypes binding of libflowfusion_amd.so and the PyTorch custom op that fronts it.
+
+The shared library (C ABI: include/flowfusion_amd.h) is the product; this module only moves
+pointers: tensors are torch-allocated device memory, the launch goes onto torch's current HIP
+stream.  There is deliberately no fallback: a missing library or a tensor that is not on the
+GPU is an error.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+from typing import List, Optional, Tuple
+
+import torch
+
+FF_OK = 0
+FF_ERR_BADARG = -1
+FF_ERR_UNSUPPORTED = -2
+FF_ERR_HIP = -3
+
+MODE_STATE = 0
+MODE_HUTCH = 1
+MODE_EXACT = 2
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libflowfusion_amd.so"
+
+
+class PlanStruct(ctypes.Structure):
+    _fields_ = [
+        ("dim", ctypes.c_int32),
+        ("cond_dim", ctypes.c_int32),
+        ("n_hidden", ctypes.c_int32),
+        ("width", ctypes.c_int32),
+        ("dregs", ctypes.c_int32),
+        ("cregs", ctypes.c_int32),
+        ("kernel_id", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class OdeArgs(ctypes.Structure):
+    _fields_ = [
+        ("x_in", ctypes.c_void_p),
+        ("x_out", ctypes.c_void_p),
+        ("cond", ctypes.c_void_p),
+        ("probe", ctypes.c_void_p),
+        ("dlogp_out", ctypes.c_void_p),
+        ("noise", ctypes.c_void_p),
+        ("wpack", ctypes.c_void_p),
+        ("etab", ctypes.c_void_p),
+        ("in_shift", ctypes.c_void_p),
+        ("in_scale", ctypes.c_void_p),
+        ("out_scale", ctypes.c_void_p),
+        ("out_shift", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
+        ("batch", ctypes.c_int64),
+        ("noise_stride", ctypes.c_int64),
+        ("n_evals", ctypes.c_int32),
+        ("mode", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("FLOWFUSION_AMD_LIB", _LIB_PATH))
+
+
+def lib() -> ctypes.CDLL:
+    """Load libflowfusion_amd.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: the HIP library is not built. Run `python -m flowfusion_amd.build` "
+            "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
+    L = ctypes.CDLL(str(path))
+    L.ff_version.restype = ctypes.c_char_p
+    L.ff_kernel_count.restype = ctypes.c_int
+    L.ff_kernel_name.restype = ctypes.c_char_p
+    L.ff_kernel_name.argtypes = [ctypes.c_int]
+    L.ff_mlp_plan.restype = ctypes.c_int
+    L.ff_mlp_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                              ctypes.c_int, ctypes.POINTER(PlanStruct)]
+    L.ff_mlp_wpack_floats.restype = ctypes.c_size_t
+    L.ff_mlp_wpack_floats.argtypes = [ctypes.POINTER(PlanStruct)]
+    L.ff_mlp_wpack.restype = ctypes.c_int
+    L.ff_mlp_wpack.argtypes = [ctypes.POINTER(PlanStruct), ctypes.POINTER(ctypes.c_void_p),
+                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.ff_mlp_ode_launch.restype = ctypes.c_int
+    L.ff_mlp_ode_launch.argtypes = [ctypes.POINTER(PlanStruct), ctypes.POINTER(OdeArgs), ctypes.c_void_p]
+    L.ff_mlp_samples_per_workgroup.restype = ctypes.c_int
+    L.ff_mlp_samples_per_workgroup.argtypes = [ctypes.POINTER(PlanStruct), ctypes.c_int]
+    L.ff_last_hip_error.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _err(rc: int, what: str) -> RuntimeError:
+    names = {FF_ERR_BADARG: "FF_ERR_BADARG", FF_ERR_UNSUPPORTED: "FF_ERR_UNSUPPORTED", FF_ERR_HIP: "FF_ERR_HIP"}
+    extra = f" (hipError {lib().ff_last_hip_error()})" if rc == FF_ERR_HIP else ""
+    return RuntimeError(f"{what} failed: {names.get(rc, rc)}{extra}")
+
+
+def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int) -> PlanStruct:
+    """ff_mlp_plan: pick the compiled kernel for this network shape (raises if none fits)."""
+    p = PlanStruct()
+    arr = (ctypes.c_int * len(hidden))(*hidden)
+    rc = lib().ff_mlp_plan(dim, cond_dim, len(hidden), arr, mode, ctypes.byref(p))
+    if rc == FF_ERR_UNSUPPORTED:
+        raise NotImplementedError(
+            f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}: "
+            "compiled shapes cover dim<=32, cond_dim<=16, hidden width<=256 "
+            "(exact-trace mode additionally needs dim<=31)")
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_plan")
+    return p
+
+
+def pack_weights(plan: PlanStruct, weights: List[torch.Tensor], biases: List[Optional[torch.Tensor]],
+                 hidden: List[int], x_col0: int, c_col0: int) -> torch.Tensor:
+    """ff_mlp_wpack on host copies of the nn.Linear parameters; returns the packed CPU tensor."""
+    L = lib()
+    n = L.ff_mlp_wpack_floats(ctypes.byref(plan))
+    out = torch.empty(n, dtype=torch.float32)
+    ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
+    bs = [None if b is None else b.detach().to("cpu", torch.float32).contiguous() for b in biases]
+    wp = (ctypes.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[0 if b is None else b.data_ptr() for b in bs])
+    hw = (ctypes.c_int * len(hidden))(*hidden)
+    rc = L.ff_mlp_wpack(ctypes.byref(plan), wp, bp, hw, int(ws[0].shape[1]), x_col0, c_col0, out.data_ptr())
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_wpack")
+    return out
+
+
+def samples_per_workgroup(plan: PlanStruct, mode: int) -> int:
+    return int(lib().ff_mlp_samples_per_workgroup(ctypes.byref(plan), mode))
+
+
+def _plan_from_words(words: List[int]) -> PlanStruct:
+    return PlanStruct(*words)
+
+
+def plan_words(plan: PlanStruct) -> List[int]:
+    return [int(getattr(plan, f)) for f, _ in PlanStruct._fields_]
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dev) -> int:
+    if t is None:
+        return 0
+    if t.device != dev:
+        raise RuntimeError(f"{name} is on {t.device}, expected {dev}")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous float32")
+    return t.data_ptr()
+
+
+@torch.library.custom_op("flowfusion_amd::mlp_ode", mutates_args=())
+def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch.Tensor],
+            noise: Optional[torch.Tensor], wpack: torch.Tensor, etab: torch.Tensor,
+            in_shift: Optional[torch.Tensor], in_scale: Optional[torch.Tensor],
+            out_scale: Optional[torch.Tensor], out_shift: Optional[torch.Tensor],
+            plan: List[int], mode: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Fused integration on the GPU: returns (final state [B,D], integrated divergence [B], status[1])."""
+    if not x.is_cuda:
+        raise RuntimeError("flowfusion_amd::mlp_ode needs tensors on the GPU (there is no CPU path)")
+    dev = x.device
+    p = _plan_from_words(plan)
+    B, D = x.shape
+    if D != p.dim:
+        raise RuntimeError(f"state has {D} columns, plan was made for {p.dim}")
+    x_out = torch.empty_like(x)
+    dlogp = torch.zeros(B if mode != MODE_STATE else 0, dtype=torch.float32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = OdeArgs()
+    a.x_in = _chk(x, "x", dev)
+    a.x_out = x_out.data_ptr()
+    a.cond = _chk(cond, "cond", dev)
+    a.probe = _chk(probe, "probe", dev)
+    a.dlogp_out = dlogp.data_ptr() if mode != MODE_STATE else 0
+    a.noise = _chk(noise, "noise", dev)
+    a.wpack = _chk(wpack, "wpack", dev)
+    a.etab = _chk(etab, "etab", dev)
+    a.in_shift = _chk(in_shift, "in_shift", dev)
+    a.in_scale = _chk(in_scale, "in_scale", dev)
+    a.out_scale = _chk(out_scale, "out_scale", dev)
+    a.out_shift = _chk(out_shift, "out_shift", dev)
+    a.status = status.data_ptr()
+    a.batch = B
+    a.noise_stride = B * D
+    a.n_evals = etab.shape[0]
+    a.mode = mode
+    if cond is not None and tuple(cond.shape) != (B, p.cond_dim):
+        raise RuntimeError(f"cond has shape {tuple(cond.shape)}, expected {(B, p.cond_dim)}")
+    if probe is not None and tuple(probe.shape) != (B, D):
+        raise RuntimeError(f"probe has shape {tuple(probe.shape)}, expected {(B, D)}")
+    if etab.shape[1] != 32 + p.width:
+        raise RuntimeError("evaluation table width does not match the plan")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_ode_launch")
+    return x_out, dlogp, status
+
+
+@mlp_ode.register_fake
+def _(x, cond, probe, noise, wpack, etab, in_shift, in_scale, out_scale, out_shift, plan, mode):
+    B = x.shape[0]
+    return (torch.empty_like(x), x.new_empty(B if mode != MODE_STATE else 0),
+            torch.empty(1, dtype=torch.int32, device=x.device))

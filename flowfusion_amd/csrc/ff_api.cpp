@@ -1,0 +1,205 @@
+// ff_api.cpp -- C ABI of libflowfusion_amd.so (see include/flowfusion_amd.h).
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+#include <stdio.h>
+#include "flowfusion_amd.h"
+#include "ff_layout.h"
+#include "ff_registry.h"
+
+static_assert(FF_MAX_SLOTS == ff::kSlots, "slot count mismatch between header and kernel");
+static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
+
+static thread_local int t_last_hip_error = 0;
+
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.1 gfx950 (f32 MFMA 32x32x2, in-register layer chaining)"; }
+
+extern "C" int ff_kernel_count(void) { return ff::g_n_kernels; }
+
+extern "C" const char* ff_kernel_name(int id)
+{
+    if (id < 0 || id >= ff::g_n_kernels) return NULL;
+    return ff::g_kernels[id].name;
+}
+
+extern "C" int ff_last_hip_error(void) { return t_last_hip_error; }
+
+static int tangents_of_mode(int mode, int dim, int* n_tangent, int* unit)
+{
+    switch (mode) {
+    case FF_MODE_STATE: *n_tangent = 0; *unit = 0; return 0;
+    case FF_MODE_HUTCH: *n_tangent = 1; *unit = 0; return 0;
+    case FF_MODE_EXACT: *n_tangent = dim; *unit = 1; return (dim + 1 <= 32) ? 0 : FF_ERR_UNSUPPORTED;
+    default: return FF_ERR_BADARG;
+    }
+}
+
+extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                           ff_mlp_plan_t* plan)
+{
+    if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
+    int nt, unit;
+    int rc = tangents_of_mode(mode, dim, &nt, &unit);
+    if (rc) return rc;
+    int wmax = 0;
+    for (int i = 0; i < n_hidden; ++i) {
+        if (hidden_widths[i] < 1) return FF_ERR_BADARG;
+        if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
+    }
+    const int need_d = ff::regs_for(dim);
+    const int need_c = cond_dim > 0 ? ff::regs_for(cond_dim) : 0;
+    const int need_t = mode != FF_MODE_STATE;
+    int best = -1;
+    for (int i = 0; i < ff::g_n_kernels; ++i) {
+        const ff::KernelEntry& k = ff::g_kernels[i];
+        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t) continue;
+        if (best < 0) { best = i; continue; }
+        const ff::KernelEntry& b = ff::g_kernels[best];
+        // cheapest first: width dominates the FLOPs, then the first-layer k-steps
+        if (k.H < b.H || (k.H == b.H && (k.dregs + k.cregs < b.dregs + b.cregs))) best = i;
+    }
+    if (best < 0) return FF_ERR_UNSUPPORTED;
+    memset(plan, 0, sizeof(*plan));
+    plan->dim = dim;
+    plan->cond_dim = cond_dim;
+    plan->n_hidden = n_hidden;
+    plan->width = ff::g_kernels[best].H;
+    plan->dregs = ff::g_kernels[best].dregs;
+    plan->cregs = ff::g_kernels[best].cregs;
+    plan->kernel_id = best;
+    return FF_OK;
+}
+
+static bool plan_ok(const ff_mlp_plan_t* p)
+{
+    if (!p || p->kernel_id < 0 || p->kernel_id >= ff::g_n_kernels) return false;
+    const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
+    return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && p->n_hidden >= 1 &&
+           p->dim >= 1 && p->dim <= 2 * p->dregs && p->cond_dim >= 0 && p->cond_dim <= 2 * p->cregs;
+}
+
+extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
+{
+    if (!plan_ok(plan)) return 0;
+    return ff::make_layout(plan->width, plan->dregs, plan->cregs, plan->n_hidden).total_floats;
+}
+
+extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
+                            const int* hidden_widths, int in_features0, int x_col0, int c_col0, float* out)
+{
+    if (!plan_ok(plan) || !W || !b || !hidden_widths || !out) return FF_ERR_BADARG;
+    const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden;
+    if (x_col0 < 0 || x_col0 + D > in_features0) return FF_ERR_BADARG;
+    if (C > 0 && (c_col0 < 0 || c_col0 + C > in_features0)) return FF_ERR_BADARG;
+    for (int i = 0; i < NH; ++i)
+        if (hidden_widths[i] < 1 || hidden_widths[i] > H) return FF_ERR_BADARG;
+    for (int i = 0; i <= NH; ++i)
+        if (!W[i] || (i > 0 && !b[i])) return FF_ERR_BADARG;
+    const ff::Layout L = ff::make_layout(H, plan->dregs, plan->cregs, NH);
+    const int NB = L.NB;
+    memset(out, 0, L.total_floats * sizeof(float));
+
+    // first layer: operand registers = [state | conditional]
+    {
+        float* o = out + L.off_l1();
+        const int KR = plan->dregs + plan->cregs;
+        const int w0 = hidden_widths[0];
+        for (int g = 0; g < KR / 4; ++g)
+            for (int ob = 0; ob < NB; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
+                        int colidx = -1;
+                        if (r < plan->dregs) {
+                            const int d = ff::feat_of_reg(r, h);
+                            if (d < D) colidx = x_col0 + d;
+                        } else {
+                            const int d = ff::feat_of_reg(r - plan->dregs, h);
+                            if (d < C) colidx = c_col0 + d;
+                        }
+                        float v = 0.f;
+                        if (row < w0 && colidx >= 0) v = W[0][(size_t)row * in_features0 + colidx];
+                        o[((size_t)(g * NB + ob) * 64 + lane) * 4 + q] = v;
+                    }
+    }
+    // hidden -> hidden
+    for (int l = 1; l < NH; ++l) {
+        float* o = out + L.off_hid(l - 1);
+        const int win = hidden_widths[l - 1], wout = hidden_widths[l];
+        for (int g = 0; g < NB * 4; ++g)
+            for (int ob = 0; ob < NB; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
+                        const int k = ff::feat_of_reg(r, h);
+                        float v = 0.f;
+                        if (row < wout && k < win) v = W[l][(size_t)row * win + k];
+                        o[((size_t)(g * NB + ob) * 64 + lane) * 4 + q] = v;
+                    }
+        float* ob_ = o + L.hid_w_floats;
+        for (int row = 0; row < wout; ++row) ob_[row] = b[l][row];
+    }
+    // output layer
+    {
+        float* o = out + L.off_out();
+        const int win = hidden_widths[NH - 1];
+        for (int g = 0; g < NB * 4; ++g)
+            for (int ob = 0; ob < L.nob_out; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
+                        const int k = ff::feat_of_reg(r, h);
+                        float v = 0.f;
+                        if (row < D && k < win) v = W[NH][(size_t)row * win + k];
+                        o[((size_t)(g * L.nob_out + ob) * 64 + lane) * 4 + q] = v;
+                    }
+        float* ob_ = o + L.out_w_floats;
+        for (int row = 0; row < D; ++row) ob_[row] = b[NH][row];
+    }
+    return FF_OK;
+}
+
+extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
+{
+    if (!plan_ok(plan)) return FF_ERR_BADARG;
+    int nt, unit;
+    int rc = tangents_of_mode(mode, plan->dim, &nt, &unit);
+    if (rc) return rc;
+    return 4 * (32 / (1 + nt));
+}
+
+extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
+{
+    if (!plan_ok(plan) || !a) return FF_ERR_BADARG;
+    if (!a->x_in || !a->x_out || !a->wpack || !a->etab || a->batch < 0 || a->n_evals < 0) return FF_ERR_BADARG;
+    if (plan->cond_dim > 0 && !a->cond) return FF_ERR_BADARG;
+    const ff::KernelEntry& k = ff::g_kernels[plan->kernel_id];
+    int nt, unit;
+    int rc = tangents_of_mode(a->mode, plan->dim, &nt, &unit);
+    if (rc) return rc;
+    if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
+    if (a->mode == FF_MODE_HUTCH && !a->probe) return FF_ERR_BADARG;
+    if (a->mode != FF_MODE_STATE && !a->dlogp_out) return FF_ERR_BADARG;
+    if (a->batch == 0) return FF_OK;
+
+    ff::KernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.x_in = a->x_in; ka.x_out = a->x_out; ka.cond = a->cond; ka.probe = a->probe;
+    ka.dlogp_out = a->dlogp_out; ka.noise = a->noise; ka.wpack = a->wpack; ka.etab = a->etab;
+    ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
+    ka.status = a->status; ka.batch = a->batch; ka.noise_stride = a->noise_stride;
+    ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
+    ka.n_tangent = nt; ka.unit_tangents = unit;
+    ka.etab_stride = FF_ROW_HDR + plan->width;
+    const ff::Layout L = ff::make_layout(plan->width, plan->dregs, plan->cregs, plan->n_hidden);
+    if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
+    if ((size_t)a->n_evals * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
+    ka.wpack_floats = (int)L.total_floats;
+
+    const long long spw = 4ll * (32 / (1 + nt));
+    const long long grid = (a->batch + spw - 1) / spw;
+    if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
+    const unsigned lds = 4u * ff::kSlots * (plan->dregs / 4) * 64 * 16;
+    const int herr = k.launch(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
+    if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
+    return FF_OK;
+}

@@ -1,0 +1,35 @@
+// ff_kernel_args.h -- argument block of the mlp_ode kernels (host + device).
+#pragma once
+#include <stdint.h>
+
+namespace ff {
+
+constexpr int kSlots = 6;   // == FF_MAX_SLOTS
+
+struct KernelArgs {
+    const float* x_in;
+    float* x_out;
+    const float* cond;
+    const float* probe;
+    float* dlogp_out;
+    const float* noise;
+    const float* wpack;
+    const float* etab;
+    const float* in_shift;
+    const float* in_scale;
+    const float* out_scale;
+    const float* out_shift;
+    uint32_t* status;
+    long long batch;
+    long long noise_stride;
+    int n_evals;
+    int n_hidden;
+    int dim;
+    int cond_dim;
+    int n_tangent;       // T: tangent columns per sample (0 in FF_MODE_STATE)
+    int unit_tangents;   // 1: tangents are unit vectors (exact trace); 0: tangent = probe[sample]
+    int etab_stride;     // floats per evaluation row = FF_ROW_HDR + H
+    int wpack_floats;    // size of wpack (bounds of the buffer resource)
+};
+
+} // namespace ff

@@ -1,0 +1,434 @@
+"""Score-based diffusion models on MI355X: the reference's ``flowfusion.diffusion`` API with the
+sampling / log-density solves running as one fused HIP launch.
+
+Class names, constructor arguments, method signatures, return shapes and ``state_dict`` keys
+follow ``flowfusion/diffusion.py`` (MLP :9-121, ScoreModel :124-815, VESDE :818-1003,
+VPSDE :1006-1180, SUBVPSDE :1183-1366, PopulationModelDiffusion[Conditional] :1466-1848) so a
+model trained with the reference loads with ``load_state_dict`` and samples here.
+
+What is native (csrc/ff_mlp_ode.hpp through the C ABI in include/flowfusion_amd.h):
+``ScoreModel.sample_ode_from_base``, ``solve_odes_forward`` / ``log_prob`` (Hutchinson probe or
+exact trace) and ``sample_sde``, for an ``MLP`` score network with SiLU activations and a
+fixed-grid ``method`` (``euler``, ``midpoint``, ``heun3``, ``rk4`` + ``options={"step_size": h}``).
+Anything else on those methods (adaptive solvers, Hutch++/XTrace, CPU tensors) raises: there is no
+eager/CPU fallback behind them.  The small pointwise members (``MLP.forward``, ``score``,
+``ode_drift``, the SDE schedule functions) are ordinary torch code, used by training code and to
+build the per-evaluation tables on the host.  Training losses and the adjoint branches of the
+reference are out of scope.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+from torch.distributions import Normal
+
+from . import solvers
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
+
+
+# ------------------------------------------------------------------------------------------------
+# score network
+# ------------------------------------------------------------------------------------------------
+class MLP(nn.Module):
+    """Score network: Gaussian-Fourier time features, then Linear/activation layers.
+
+    Same parameters and buffers as the reference (diffusion.py:32-80): ``NN`` (ModuleList of
+    Linear), ``W`` (frozen embedding frequencies, ``embedding_dimensions // 2`` of them drawn as
+    ``randn * sigma_initialization``) and ``pi``.  Input column order of the first layer is
+    ``[sin, cos, x, conditional]`` (diffusion.py:109-113).
+    """
+
+    def __init__(self, n_dimensions=2, n_conditionals=1, embedding_dimensions=8, units=[128],
+                 activation=nn.SiLU(), sigma_initialization=16):
+        super().__init__()
+        self.n_dimensions = n_dimensions
+        self.n_conditionals = n_conditionals
+        self.architecture = [n_dimensions + n_conditionals + embedding_dimensions] + list(units) + [n_dimensions]
+        self.n_layers = len(self.architecture) - 1
+        self.NN = nn.ModuleList(
+            nn.Linear(n_in, n_out) for n_in, n_out in zip(self.architecture[:-1], self.architecture[1:]))
+        self.W = nn.Parameter(torch.randn(embedding_dimensions // 2) * sigma_initialization, requires_grad=False)
+        self.activation = activation
+        self.register_buffer("pi", torch.tensor(math.pi, dtype=torch.float32))
+
+    def time_features(self, t):
+        """[sin(2 pi W t), cos(2 pi W t)] with the reference's fp32 operation order (diffusion.py:109-110)."""
+        arg = t[:, None] * self.W[None, :] * 2 * self.pi
+        return torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+
+    def forward(self, t, x, conditional=None):
+        if conditional is not None:
+            x = torch.cat([x, conditional], dim=1)
+        if t.dim() == 0:
+            t = t * torch.ones(x.shape[:-1], device=x.device)
+        h = torch.cat([self.time_features(t), x], dim=1)
+        for layer in self.NN[:-1]:
+            h = self.activation(layer(h))
+        return self.NN[-1](h)
+
+
+# ------------------------------------------------------------------------------------------------
+# SDEs (closed-form schedules; reference: diffusion.py:818-1366)
+# ------------------------------------------------------------------------------------------------
+def _col(v, x):
+    return v.view(-1, *[1] * (x.dim() - 1))
+
+
+class VESDE(nn.Module):
+    """Variance-exploding SDE: sigma(t) = sigma_min (sigma_max/sigma_min)^(t/T), zero drift."""
+
+    def __init__(self, sigma_min=1e-2, sigma_max=10.0, T=1.0, epsilon=1e-5):
+        super().__init__()
+        for name, val in (("T", T), ("epsilon", epsilon), ("sigma_min", sigma_min), ("sigma_max", sigma_max)):
+            self.register_buffer(name, torch.tensor(val, dtype=torch.float32))
+
+    def sigma(self, t):
+        return self.sigma_min * (self.sigma_max / self.sigma_min) ** (t / self.T)
+
+    def diffusion(self, t, x):
+        return _col(self.sigma(t), x) * torch.sqrt(2 * (torch.log(self.sigma_max) - torch.log(self.sigma_min)) / self.T)
+
+    def drift(self, t, x):
+        return torch.zeros_like(x)
+
+    def marginal_prob_scalars(self, t):
+        return torch.ones_like(t), self.sigma(t)
+
+    def marginal_prob(self, t, x):
+        m, s = self.marginal_prob_scalars(t)
+        return _col(m, x) * x, _col(s, x)
+
+    def sample_marginal(self, t, x0):
+        m, s = self.marginal_prob_scalars(t)
+        return _col(m, x0) * x0 + _col(s, x0) * torch.randn_like(x0)
+
+    def prior(self, shape, mu=None):
+        if mu is None:
+            mu = torch.zeros(shape, device=self.T.device)
+        else:
+            assert mu.shape == shape
+        return Normal(loc=mu, scale=self.sigma_max)
+
+
+class VPSDE(nn.Module):
+    """Variance-preserving SDE with linear beta(t); ``beta_min/beta_max/T`` are plain floats and
+    ``epsilon`` a buffer, as in the reference (diffusion.py:1042-1045)."""
+
+    def __init__(self, beta_min=0.1, beta_max=20, T=1.0, epsilon=1e-3):
+        super().__init__()
+        self.beta_min = beta_min
+        self.beta_max = beta_max
+        self.T = T
+        self.register_buffer("epsilon", torch.tensor(epsilon, dtype=torch.float32))
+
+    def beta(self, t):
+        return self.beta_min + (self.beta_max - self.beta_min) * (t / self.T)
+
+    def _log_coeff(self, t):
+        return 0.5 * (self.beta_max - self.beta_min) * t ** 2 / self.T + self.beta_min * t
+
+    def marginal_prob_scalars(self, t):
+        lc = self._log_coeff(t)
+        return torch.exp(-0.5 * lc), torch.sqrt(1.0 - torch.exp(-lc))
+
+    def sigma(self, t):
+        return self.marginal_prob_scalars(t)[1]
+
+    def prior(self, shape):
+        return Normal(loc=torch.zeros(shape, device=self.epsilon.device), scale=1.0)
+
+    def diffusion(self, t, x):
+        return _col(torch.sqrt(self.beta(t)), x)
+
+    def drift(self, t, x):
+        return -0.5 * _col(self.beta(t), x) * x
+
+    def marginal_prob(self, t, x):
+        m, s = self.marginal_prob_scalars(t)
+        return _col(m, x) * x, _col(s, x)
+
+
+class SUBVPSDE(VPSDE):
+    """Sub-VP SDE: same drift as VP, g^2 = beta (1 - exp(-2 int beta)), std = 1 - exp(-int beta)."""
+
+    def diffusion(self, t, x):
+        decay = torch.exp(-2 * self.beta_min * t - (self.beta_max - self.beta_min) * t ** 2 / self.T)
+        return _col(torch.sqrt(self.beta(t) * (1.0 - decay)), x)
+
+    def marginal_prob_scalars(self, t):
+        lc = self._log_coeff(t)
+        return torch.exp(-0.5 * lc), 1.0 - torch.exp(-lc)
+
+
+# ------------------------------------------------------------------------------------------------
+# score model
+# ------------------------------------------------------------------------------------------------
+class ScoreModel(nn.Module):
+    """Sampler / density evaluator for a score network and an SDE (reference: diffusion.py:124-815)."""
+
+    def __init__(self, model=None, sde=None, conditional=None, no_sigma=False, hutchinson=False,
+                 hutchpp=False, hpp_rank=1, hpp_vecs=1, xtrace=False, xt_vecs=1):
+        super().__init__()
+        self.model = model
+        self.sde = sde
+        self.conditional = conditional
+        self.no_sigma = no_sigma
+        self.prob = False
+        self.hutch = hutchinson
+        self.hutchpp = hutchpp
+        self.hpp_rank = hpp_rank
+        self.hpp_vector = hpp_vecs
+        self.xtrace = xtrace
+        self.xt_vector = xt_vecs
+        self._fused = None
+
+    # -- pointwise pieces (plain torch) -------------------------------------------------------
+    def score(self, t, x, conditional=None):
+        out = self.model(t, x, conditional=conditional)
+        if self.no_sigma:
+            return out
+        return out / _col(self.sde.sigma(t), x)
+
+    def ode_drift(self, t, x, conditional=None):
+        g = self.sde.diffusion(t, x)
+        return self.sde.drift(t, x) - 0.5 * g ** 2 * self.score(t, x, conditional=conditional)
+
+    def forward(self, t, states):
+        """ODE right-hand side in torchdiffeq's calling convention: ``states = (x,)`` or
+        ``(x, dlogp)``; returns the matching tuple of time derivatives (reference :281-508).
+        Autograd-based and differentiable; the fused solves do not call it."""
+        x = states[0]
+        if not self.prob:
+            with torch.set_grad_enabled(True):
+                x.requires_grad_(True)
+                return self.ode_drift(t, x, conditional=self.conditional)
+        if self.hutchpp or self.xtrace:
+            raise NotImplementedError("Hutch++ / XTrace trace estimators are outside the MI355X hot path")
+        n = x.shape[0]
+        with torch.set_grad_enabled(True):
+            x.requires_grad_(True)
+            xdot = self.ode_drift(t, x, conditional=self.conditional)
+            if self.hutch:
+                vjp = torch.autograd.grad(xdot, x, self.e, create_graph=True, retain_graph=True)[0]
+                div = (vjp * self.e).sum(dim=1)
+            else:
+                div = x.new_zeros(n)
+                for i in range(x.shape[1]):
+                    div = div + torch.autograd.grad(xdot[:, i].sum(), x, create_graph=True, retain_graph=True)[0][:, i]
+        return xdot, div.view(n, 1)
+
+    # -- fused path -----------------------------------------------------------------------------
+    def _net(self) -> FusedNet:
+        m = self.model
+        if not (hasattr(m, "NN") and hasattr(m, "W") and hasattr(m, "pi") and hasattr(m, "n_dimensions")):
+            raise NotImplementedError(
+                "the fused gfx950 path needs a flowfusion MLP score network "
+                f"(NN/W/pi attributes); got {type(m).__name__}")
+        _require_silu(m.activation)
+        if self._fused is None or self._fused.linears[0] is not m.NN[0]:
+            E = 2 * m.W.numel()
+            self._fused = FusedNet(list(m.NN), m.n_dimensions, m.n_conditionals, x_col0=E,
+                                   c_col0=E + m.n_dimensions)
+        return self._fused
+
+    def _schedule(self, t: torch.Tensor, sde_form: str):
+        """Per-evaluation scalars (a, b) and first-layer bias c1 for real times ``t`` (fp32, CPU).
+
+        ODE (diffusion.py:276-278): xdot = f - 0.5 g^2 score  ->  a = f/x, b = -0.5 g^2 [/ sigma]
+        reverse SDE (:553):         f - g^2 score             ->  b = -g^2 [/ sigma]
+        with f = a(t) x for all three SDEs (:905, :1131, :1316).  Returns also g (for the noise).
+        """
+        sde = copy.deepcopy(self.sde).to("cpu")
+        one = torch.ones(t.numel(), 1, dtype=torch.float32)
+        a = sde.drift(t, one).reshape(-1)
+        g = sde.diffusion(t, one).reshape(-1)
+        b = -(0.5 * g ** 2) if sde_form == "ode" else -(g ** 2)
+        if not self.no_sigma:
+            b = b / sde.sigma(t).reshape(-1)
+        m = self.model
+        W = m.W.detach().to("cpu", torch.float32)
+        pi = m.pi.detach().to("cpu", torch.float32)
+        arg = t[:, None] * W[None, :] * 2 * pi
+        emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+        w0, b0 = self._net().first_layer_cpu()
+        c1 = emb @ w0[:, : emb.shape[1]].T + b0
+        return a, b, c1, g
+
+    def _check_inputs(self, x, what):
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError(
+                f"{what}: gradients through the fused solve are not available (the reference's "
+                "odeint_adjoint branch, diffusion.py:620-629, is out of scope); detach the input")
+
+    def _ode_table(self, t_span, method, options, mode):
+        plan = solvers.plan_ode(t_span, method, options)
+        a, b, c1, _ = self._schedule(plan.t_eval, "ode")
+        return solvers.build_table(plan, a, b, c1, self._net().width(mode))
+
+    @torch.no_grad()
+    def sample_sde(self, shape, conditional=None, steps=100):
+        """Euler-Maruyama sampling of the reverse SDE; returns the last *mean* state, like the
+        reference (diffusion.py:510-563).  Random numbers are drawn exactly as the reference draws
+        them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
+        ``torch.manual_seed`` reproduces the reference's GPU stream."""
+        batch, *dims = shape
+        net = self._net()
+        dev = next(self.model.parameters()).device
+        x = self.sde.prior(dims).sample([batch]).to(dev)
+        if x.dim() != 2:
+            raise NotImplementedError("sample_sde: only [batch, dim] states are supported")
+        T = torch.as_tensor(self.sde.T, dtype=torch.float32).cpu()
+        eps = self.sde.epsilon.detach().cpu()
+        ts, dt = solvers.plan_euler_maruyama(T, eps, steps)
+        n = int(ts.numel())
+        if n == 0:
+            raise RuntimeError("sample_sde: T < epsilon, no step to take")
+        a, b, c1, g = self._schedule(ts, "sde")
+        sqrt_mdt = (-dt) ** (1.0 / 2.0)
+        # rows: one evaluation per step; x_mean = x + f dt ; x = x_mean + g dw
+        zeros8 = torch.zeros(n, 8)
+        cout = zeros8.clone()
+        cout[:, 0] = dt
+        plan = solvers.EvalPlan(t_eval=ts, sign=1.0, slot=torch.zeros(n, dtype=torch.int32),
+                                flags=torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32),
+                                cin=zeros8, cout=cout, n_steps=n)
+        plan.flags[-1] = solvers.FLAG_STEP_END            # the returned state is x_mean of the last step
+        gn = g * sqrt_mdt
+        # noise slabs are drawn per step, in order, on the device -- chunked to bound memory
+        per_step = batch * x.shape[1]
+        chunk = max(1, min(n, (1 << 29) // max(per_step, 1)))
+        start = 0
+        status_any = None
+        while start < n:
+            stop = min(n, start + chunk)
+            noise = torch.empty(stop - start, batch, x.shape[1], device=dev, dtype=torch.float32)
+            for i in range(stop - start):      # one draw per executed step, the last included (:554)
+                noise[i] = torch.randn_like(x)
+            sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=plan.slot[start:stop],
+                                   flags=plan.flags[start:stop], cin=plan.cin[start:stop],
+                                   cout=plan.cout[start:stop], n_steps=stop - start)
+            table = solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
+                                        gn=gn[start:stop], noise_idx=torch.arange(stop - start))
+            x, _, status = net.integrate(x, table, MODE_STATE, cond=conditional, noise=noise)
+            status_any = status if status_any is None else (status_any | status)
+            start = stop
+        if int(status_any.item()) & 1:
+            print("Diffusion is not stable, NaN were produced. Stopped sampling.")
+        return x
+
+    def sample_ode_from_base(self, base_samples, conditional=None, atol=1e-4, rtol=1e-4,
+                             method="dopri5", options=None):
+        """Probability-flow ODE from t=1 down to epsilon; returns ``(samples, [])`` like the
+        reference (diffusion.py:566-640).  ``atol``/``rtol`` are accepted for signature
+        compatibility and unused by the fixed-grid methods."""
+        self._check_inputs(base_samples, "sample_ode_from_base")
+        net = self._net()
+        z = base_samples * self.sde.sigma_max if hasattr(self.sde, "sigma_max") else base_samples
+        self.prob = False
+        self.conditional = conditional
+        t_span = torch.tensor([1.0, float(self.sde.epsilon)], dtype=torch.float32)
+        table = self._ode_table(t_span, method, options, MODE_STATE)
+        x, _, _ = net.integrate(z, table, MODE_STATE, cond=conditional)
+        return x, []
+
+    @torch.no_grad()
+    def solve_odes_forward(self, x0_samples, conditional=None, atol=1e-5, rtol=1e-5,
+                           method="dopri5", options=None):
+        """Probability-flow ODE from epsilon up to t=1 with the divergence integrated alongside;
+        returns ``(xT, delta_logp[B,1])`` (reference: diffusion.py:642-754)."""
+        net = self._net()
+        self.prob = True
+        self.conditional = conditional
+        if self.hutchpp or self.xtrace:
+            raise NotImplementedError("Hutch++ / XTrace trace estimators are outside the MI355X hot path "
+                                      "(use hutchinson=True or the exact trace)")
+        probe = None
+        mode = MODE_EXACT
+        if self.hutch:
+            # drawn on the CPU and moved, as the reference does (diffusion.py:701)
+            self.e = torch.sign(torch.randn(x0_samples.shape)).to(x0_samples.device)
+            probe = self.e
+            mode = MODE_HUTCH
+        t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
+        table = self._ode_table(t_span, method, options, mode)
+        xT, dlogp, _ = net.integrate(x0_samples, table, mode, cond=conditional, probe=probe)
+        return xT, dlogp.view(-1, 1)
+
+    @torch.no_grad()
+    def log_prob(self, x0_samples, conditional=None, atol=1e-4, rtol=1e-4, method="dopri5",
+                 options={"min_step": 1e-6}):
+        """log p(x0) = delta_logp + log prior(xT), shape [B,1] (reference: diffusion.py:756-815)."""
+        xT, lp = self.solve_odes_forward(x0_samples, conditional=conditional, atol=atol, rtol=rtol,
+                                         method=method, options=options)
+        return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), dim=1, keepdim=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# population-model wrappers (affine pre/post-processing; reference: diffusion.py:1466-1848)
+# ------------------------------------------------------------------------------------------------
+class PopulationModelDiffusion(nn.Module):
+    def __init__(self, model=None, sde=None, shift=None, scale=None, method="dopri5", no_sigma=False,
+                 hutchinson=False, options=None):
+        super().__init__()
+        self.model = model
+        self.sde = sde
+        self.score_model = ScoreModel(model=self.model, sde=self.sde, hutchinson=hutchinson, no_sigma=no_sigma)
+        n = self.model.n_dimensions
+        self.register_buffer("shift", shift if shift is not None else torch.zeros(n, dtype=torch.float32))
+        self.register_buffer("scale", scale if scale is not None else torch.ones(n, dtype=torch.float32))
+        self.method = method
+        self.options = options
+
+    def forward(self, base_samples):
+        x, _ = self.score_model.sample_ode_from_base(base_samples, method=self.method, atol=1e-5, rtol=1e-5,
+                                                     options=self.options)
+        return x * self.scale + self.shift
+
+    def sample_sde(self, shape, steps=100):
+        # the reference ignores `steps` here and always takes 100 (diffusion.py:1608)
+        return self.score_model.sample_sde(shape, steps=100) * self.scale + self.shift
+
+    def log_prob(self, x, atol=1e-5, rtol=1e-5):
+        # the reference does not forward self.method here: the solver default applies (diffusion.py:1633-1635)
+        xT, lp = self.score_model.solve_odes_forward((x - self.shift) / self.scale, atol=atol, rtol=rtol,
+                                                     options=self.options)
+        return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), 1, keepdim=True)
+
+
+class PopulationModelDiffusionConditional(nn.Module):
+    def __init__(self, model=None, sde=None, shift=None, scale=None, conditional_shift=None,
+                 conditional_scale=None, no_sigma=False, method="dopri5", options=None):
+        super().__init__()
+        self.model = model
+        self.sde = sde
+        self.score_model = ScoreModel(model=self.model, sde=self.sde, no_sigma=no_sigma)
+        n, c = self.model.n_dimensions, self.model.n_conditionals
+        self.register_buffer("shift", shift if shift is not None else torch.zeros(n, dtype=torch.float32))
+        self.register_buffer("scale", scale if scale is not None else torch.ones(n, dtype=torch.float32))
+        self.register_buffer("conditional_shift",
+                             conditional_shift if conditional_shift is not None else torch.zeros(c, dtype=torch.float32))
+        self.register_buffer("conditional_scale",
+                             conditional_scale if conditional_scale is not None else torch.ones(c, dtype=torch.float32))
+        self.options = options
+        self.method = method
+
+    def _cond(self, conditional):
+        return (conditional - self.conditional_shift) / self.conditional_scale
+
+    def forward(self, base_samples, conditional=None):
+        x, _ = self.score_model.sample_ode_from_base(base_samples, conditional=self._cond(conditional),
+                                                     method=self.method, atol=1e-5, rtol=1e-5, options=self.options)
+        return x * self.scale + self.shift
+
+    def sample_sde(self, shape, conditional=None, steps=100):
+        return self.score_model.sample_sde(shape, conditional=self._cond(conditional), steps=100) * self.scale + self.shift
+
+    def log_prob(self, x, conditional=None, atol=1e-5, rtol=1e-5):
+        xT, lp = self.score_model.solve_odes_forward((x - self.shift) / self.scale,
+                                                     conditional=self._cond(conditional), atol=atol, rtol=rtol,
+                                                     options=self.options)
+        return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), 1, keepdim=True)

@@ -1,0 +1,220 @@
+"""Flow-matching continuous normalising flows on MI355X: the reference's ``flowfusion.flow`` API
+(``ODEFlow`` flow.py:9-438, ``ConditionalODEFlow`` flow.py:441-941) with ``sample`` and
+``log_prob`` / ``solve_ode_forward`` running as one fused HIP launch.
+
+The velocity network takes ``[x, t]`` (``[x, t, (cond - shift)/scale]`` when conditional,
+flow.py:112-115, 583-586).  ``state_dict`` keys match the reference: ``twopi``,
+``target_shift``/``target_scale`` (+ ``conditional_*``), and the Linear parameters under both
+``layers.{0,2,..}`` and ``velocity.{0,2,..}`` (the same modules registered twice).
+
+Native: ``sample`` (t: 1 -> 0) and ``solve_ode_forward`` / ``log_prob`` (t: 0 -> 1, exact
+divergence by forward-mode tangents, or a Hutchinson probe as an opt-in extension) for SiLU
+networks and fixed-grid methods.  The reference's ``sample`` exposes no solver arguments and
+always runs adaptive dopri5 at torchdiffeq's default tolerances (flow.py:299-303); here ``sample``
+takes optional ``method``/``options`` keywords.  Nothing on these methods falls back to eager
+PyTorch or the CPU: unsupported requests raise.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import solvers
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
+
+_DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
+
+
+def _build_layers(sizes, activation):
+    layers = nn.ModuleList()
+    for n_in, n_out in zip(sizes[:-2], sizes[1:-1]):
+        layers.append(nn.Linear(n_in, n_out))
+        layers.append(activation())
+    layers.append(nn.Linear(sizes[-2], sizes[-1]))
+    return layers
+
+
+class _FlowBase(nn.Module):
+    """Common fused plumbing of the two flow classes."""
+
+    def _linears(self):
+        return [m for m in self.layers if isinstance(m, nn.Linear)]
+
+    def _net(self) -> FusedNet:
+        for m in self.layers:
+            if not isinstance(m, nn.Linear):
+                _require_silu(m)
+        lin = self._linears()
+        cached = getattr(self, "_fused", None)
+        if cached is None or cached.linears[0] is not lin[0]:
+            D = self.target_dimension
+            C = getattr(self, "conditional_dimension", 0)
+            # first-layer columns: [x (D) | t (1) | cond (C)]
+            object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1))
+        return self._fused
+
+    def _table(self, t_span, method, options, mode):
+        net = self._net()
+        plan = solvers.plan_ode(t_span, method, options)
+        w0, b0 = net.first_layer_cpu()
+        D = self.target_dimension
+        t = plan.t_eval
+        c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
+        zeros = torch.zeros_like(t)
+        return solvers.build_table(plan, zeros, torch.ones_like(t), c1, net.width(mode))
+
+    def _norm_cond(self, conditional):
+        return (conditional - self.conditional_shift) / self.conditional_scale
+
+    def _fused_sample(self, xT, conditional, method, options):
+        if torch.is_grad_enabled() and xT.requires_grad:
+            raise NotImplementedError("gradients through the fused solve are not available; detach the input")
+        method = _DEFAULT_SAMPLE_METHOD if method is None else method
+        t_span = torch.tensor([1.0, 0.0], dtype=torch.float32)
+        table = self._table(t_span, method, options, MODE_STATE)
+        x, _, _ = self._net().integrate(xT, table, MODE_STATE, cond=conditional,
+                                        out_scale=self.target_scale, out_shift=self.target_shift)
+        return x
+
+    def _fused_forward(self, x, conditional, method, options, hutchinson):
+        t_span = torch.tensor([0.0, 1.0], dtype=torch.float32)
+        mode, probe = MODE_EXACT, None
+        if hutchinson:
+            mode = MODE_HUTCH
+            probe = torch.sign(torch.randn(x.shape)).to(x.device)
+        table = self._table(t_span, method, options, mode)
+        xT, logj, _ = self._net().integrate(x, table, mode, cond=conditional, probe=probe)
+        return xT, logj.view(-1, 1)
+
+
+class ODEFlow(_FlowBase):
+    """Unconditional flow-matching CNF (reference: flow.py:9-438)."""
+
+    def __init__(self, target_dimension: int = 1, hidden_units: List[int] = [128, 128],
+                 activation: nn.Module = nn.SiLU, target_shift: Optional[torch.Tensor] = None,
+                 target_scale: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.target_dimension = target_dimension
+        self.layers = _build_layers([target_dimension + 1] + list(hidden_units) + [target_dimension], activation)
+        self.velocity = nn.Sequential(*self.layers)
+        self.register_buffer("twopi", torch.tensor(2.0 * 3.14159265358979323846))
+        self.register_buffer("target_shift", target_shift if target_shift is not None else torch.zeros(target_dimension))
+        self.register_buffer("target_scale", target_scale if target_scale is not None else torch.ones(target_dimension))
+
+    # -- pointwise (plain torch) ----------------------------------------------------------------
+    def dynamics(self, t: torch.Tensor, states: Tuple[torch.Tensor]):
+        x = states[0]
+        return self.velocity(torch.cat([x, t.view(-1, 1).expand(x.shape[0], 1)], dim=1))
+
+    def dynamics_with_jacobian(self, t, states):
+        x, logj = states
+        with torch.set_grad_enabled(True):
+            x.requires_grad_(True)
+            v = self.dynamics(t, (x,))
+            div = torch.zeros_like(logj)
+            for i in range(x.shape[-1]):
+                div = div + torch.autograd.grad(v[:, i].sum(), x, create_graph=True, retain_graph=True)[0][:, i:i + 1]
+        return v, div
+
+    def forward(self, t, states):
+        return self.dynamics(t, states)
+
+    def compute_linear_velocity_field(self, x0, xT, t):
+        x0 = (x0 - self.target_shift) / self.target_scale
+        return (1 - t) * x0 + t * xT, xT - x0
+
+    # -- fused ------------------------------------------------------------------------------------
+    def sample(self, xT: torch.Tensor, gradients: bool = False, method: Optional[str] = None,
+               options: Optional[dict] = None):
+        """Transport base samples xT (t=1) to the target (t=0), then ``* target_scale + target_shift``."""
+        if gradients:
+            raise NotImplementedError("sample(gradients=True) uses odeint_adjoint in the reference "
+                                      "(flow.py:286-295); differentiable solves are out of scope")
+        return self._fused_sample(xT, None, method, options)
+
+    def solve_ode_forward(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
+                          options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
+        """Integrate t: 0 -> 1 with the divergence; returns ``(xT, log_jacobian[B,1])`` (flow.py:308-384)."""
+        if adjoint:
+            raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
+        return self._fused_forward(x, None, method, options, hutchinson)
+
+    def log_prob(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
+                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
+        """Log-density of target-space points, shape [B] (flow.py:386-438)."""
+        x = (x - self.target_shift) / self.target_scale
+        xT, logj = self.solve_ode_forward(x, atol, rtol, method, options, adjoint, hutchinson=hutchinson)
+        base = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
+        return base + logj.squeeze(1) - torch.sum(torch.log(self.target_scale))
+
+
+class ConditionalODEFlow(_FlowBase):
+    """Conditional flow-matching CNF (reference: flow.py:441-941)."""
+
+    def __init__(self, target_dimension: int = 1, conditional_dimension: int = 1,
+                 hidden_units: List[int] = [128, 128], activation: nn.Module = nn.SiLU,
+                 target_shift: Optional[torch.Tensor] = None, target_scale: Optional[torch.Tensor] = None,
+                 conditional_shift: Optional[torch.Tensor] = None,
+                 conditional_scale: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.target_dimension = target_dimension
+        self.conditional_dimension = conditional_dimension
+        self.layers = _build_layers(
+            [target_dimension + 1 + conditional_dimension] + list(hidden_units) + [target_dimension], activation)
+        self.velocity = nn.Sequential(*self.layers)
+        self.register_buffer("twopi", torch.tensor(2.0 * 3.14159265358979323846))
+        self.register_buffer("target_shift", target_shift if target_shift is not None else torch.zeros(target_dimension))
+        self.register_buffer("target_scale", target_scale if target_scale is not None else torch.ones(target_dimension))
+        self.register_buffer("conditional_shift",
+                             conditional_shift if conditional_shift is not None else torch.zeros(conditional_dimension))
+        self.register_buffer("conditional_scale",
+                             conditional_scale if conditional_scale is not None else torch.ones(conditional_dimension))
+
+    # -- pointwise (plain torch) ----------------------------------------------------------------
+    def dynamics(self, t, states):
+        x, conditional = states
+        c = self._norm_cond(conditional)
+        v = self.velocity(torch.cat([x, t.view(-1, 1).expand(x.shape[0], 1), c], dim=1))
+        return v, torch.zeros_like(c)
+
+    def dynamics_with_jacobian(self, t, states):
+        x, conditional, logj = states
+        with torch.set_grad_enabled(True):
+            x.requires_grad_(True)
+            v = self.dynamics(t, (x, conditional))[0]
+            div = torch.zeros_like(logj)
+            for i in range(x.shape[-1]):
+                div = div + torch.autograd.grad(v[:, i].sum(), x, create_graph=True, retain_graph=True)[0][:, i:i + 1]
+        return v, torch.zeros_like(conditional), div
+
+    def forward(self, t, states):
+        return self.dynamics(t, states)
+
+    def compute_linear_velocity_field(self, x0, xT, t):
+        x0 = (x0 - self.target_shift) / self.target_scale
+        return (1 - t) * x0 + t * xT, xT - x0
+
+    # -- fused ------------------------------------------------------------------------------------
+    def sample(self, xT, conditional, gradients: bool = False, method: Optional[str] = None,
+               options: Optional[dict] = None):
+        if gradients:
+            raise NotImplementedError("sample(gradients=True) uses odeint_adjoint in the reference "
+                                      "(flow.py:779-788); differentiable solves are out of scope")
+        return self._fused_sample(xT, self._norm_cond(conditional), method, options)
+
+    def solve_ode_forward(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5,
+                          method: str = "dopri5", options: Optional[dict] = None, adjoint: bool = False,
+                          hutchinson: bool = False):
+        if adjoint:
+            raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
+        return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson)
+
+    def log_prob(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
+                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
+        x = (x - self.target_shift) / self.target_scale
+        xT, logj = self.solve_ode_forward(x, conditional, atol, rtol, method, options, adjoint,
+                                          hutchinson=hutchinson)
+        base = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
+        return base + logj.squeeze(1) - torch.sum(torch.log(self.target_scale))

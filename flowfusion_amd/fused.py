@@ -1,0 +1,103 @@
+"""Shared host plumbing between the score-model and flow front ends.
+
+``FusedNet`` owns what the kernel needs from a Linear/SiLU stack: the kernel plan, the
+weights repacked into MFMA operand order (cached on the device, refreshed when a parameter
+changes) and the launch itself.  The front ends (diffusion.py, flow.py) supply the
+time-dependent part: one evaluation table per solve (solvers.py).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _native
+from ._native import MODE_EXACT, MODE_HUTCH, MODE_STATE  # noqa: F401  (re-exported)
+
+
+def _require_silu(act) -> None:
+    ok = isinstance(act, nn.SiLU) or act is nn.SiLU
+    if not ok:
+        raise NotImplementedError(
+            f"activation {act!r}: the fused gfx950 kernels implement SiLU (the reference default, "
+            "diffusion.py:38, flow.py:41) only")
+
+
+class FusedNet:
+    """Kernel-side view of ``Linear -> SiLU -> ... -> Linear`` with first-layer input
+    ``[ time part | x | cond ]`` in any column order."""
+
+    def __init__(self, linears: Sequence[nn.Linear], dim: int, cond_dim: int, x_col0: int, c_col0: int):
+        self.linears = list(linears)
+        if len(self.linears) < 2:
+            raise NotImplementedError("the fused path needs at least one hidden layer")
+        self.dim = int(dim)
+        self.cond_dim = int(cond_dim)
+        self.x_col0 = int(x_col0)
+        self.c_col0 = int(c_col0)
+        self.hidden = [int(l.out_features) for l in self.linears[:-1]]
+        if int(self.linears[-1].out_features) != self.dim:
+            raise ValueError("last layer must produce `dim` outputs")
+        for l in self.linears:
+            if l.bias is None:
+                raise NotImplementedError("Linear layers without bias are not supported")
+        self._plans = {}
+        self._wpack = None          # (key, device tensor)
+
+    # -- plan / weights ---------------------------------------------------------------------
+    def plan(self, mode: int) -> _native.PlanStruct:
+        key = 0 if mode == MODE_STATE else (1 if mode == MODE_HUTCH else 2)
+        if key not in self._plans:
+            self._plans[key] = _native.make_plan(self.dim, self.cond_dim, self.hidden, mode)
+        return self._plans[key]
+
+    def _param_key(self, device, plan) -> Tuple:
+        vers = tuple((p.data_ptr(), p._version) for l in self.linears for p in (l.weight, l.bias))
+        return (str(device), plan.width, plan.dregs, plan.cregs, vers)
+
+    def wpack(self, device, mode: int) -> torch.Tensor:
+        plan = self.plan(mode)
+        key = self._param_key(device, plan)
+        if self._wpack is None or self._wpack[0] != key:
+            packed = _native.pack_weights(
+                plan, [l.weight for l in self.linears], [l.bias for l in self.linears],
+                self.hidden, self.x_col0, self.c_col0)
+            self._wpack = (key, packed.to(device))
+        return self._wpack[1]
+
+    # -- launch -----------------------------------------------------------------------------
+    def integrate(self, x: torch.Tensor, etab: torch.Tensor, mode: int = MODE_STATE,
+                  cond: Optional[torch.Tensor] = None, probe: Optional[torch.Tensor] = None,
+                  noise: Optional[torch.Tensor] = None,
+                  in_shift=None, in_scale=None, out_scale=None, out_shift=None):
+        """Run the fused integration.  Returns (y_final [B,D], dlogp [B] or empty, status [1])."""
+        if not x.is_cuda:
+            raise RuntimeError(
+                "flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
+                f"(got a tensor on {x.device}); there is no CPU fallback")
+        if x.dim() != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"expected a [batch, {self.dim}] state, got {tuple(x.shape)}")
+        dev = x.device
+        plan = self.plan(mode)
+        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+        if self.cond_dim > 0:
+            if cond is None:
+                raise ValueError("this network has conditional inputs; `conditional` is required")
+            cond = f32(cond)
+            if cond.dim() != 2 or cond.shape != (x.shape[0], self.cond_dim):
+                raise ValueError(f"conditional must be [batch, {self.cond_dim}], got {tuple(cond.shape)}")
+        else:
+            cond = None
+        return torch.ops.flowfusion_amd.mlp_ode(
+            f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
+            f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift),
+            _native.plan_words(plan), mode)
+
+    # -- first layer pieces used by the table builders ---------------------------------------
+    def first_layer_cpu(self):
+        l0 = self.linears[0]
+        return (l0.weight.detach().to("cpu", torch.float32), l0.bias.detach().to("cpu", torch.float32))
+
+    def width(self, mode: int = MODE_STATE) -> int:
+        return int(self.plan(mode).width)

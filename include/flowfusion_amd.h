@@ -1,0 +1,148 @@
+/*
+ * flowfusion_amd.h -- C ABI of the MI355X (gfx950) sampling / log-density hot path.
+ *
+ * This is the drop-in boundary for flowfusion's probability-flow ODE / reverse-SDE
+ * sampling and log-density path.  The reference (Cosmo-Pop/flowfusion) is pure Python
+ * and has no FFI; what a native replacement has to take over is the time-stepping loop
+ * that the reference delegates to torchdiffeq / runs in Python:
+ *
+ *   ScoreModel.sample_ode_from_base   flowfusion/diffusion.py:566-640  (odeint call :631-639)
+ *   ScoreModel.solve_odes_forward     flowfusion/diffusion.py:642-754  (odeint call :744-752)
+ *   ScoreModel.sample_sde             flowfusion/diffusion.py:510-563  (Python EM loop :543-562)
+ *   ScoreModel.forward (ODE RHS)      flowfusion/diffusion.py:281-334,505-508
+ *   MLP.forward                       flowfusion/diffusion.py:82-121
+ *   ODEFlow.sample / solve_ode_forward            flowfusion/flow.py:259-306, 308-384
+ *   ConditionalODEFlow.sample / solve_ode_forward flowfusion/flow.py:750-799, 801-883
+ *   ODEFlow.dynamics / ConditionalODEFlow.dynamics flowfusion/flow.py:89-120, 553-596
+ *
+ * One fused kernel family ("mlp_ode") covers all of them.  It integrates, for every
+ * sample independently,
+ *
+ *        dy/ds = a_e * y + b_e * NET(y, cond ; c1_e)            (e = RHS evaluation index)
+ *
+ * where NET is the Linear/SiLU stack of the reference's MLP with the part of the first
+ * layer that depends only on time (time embedding or the raw `t` column, plus bias)
+ * pre-reduced on the host into the per-evaluation vector c1_e, and (a_e, b_e) are the
+ * scalar SDE schedule terms (-beta/2, -g^2/(2 sigma), ...; 0 and 1 for the flows).  The
+ * whole explicit Runge-Kutta / Euler-Maruyama loop runs on-chip: the state is read from
+ * HBM once and written once.
+ *
+ * Conventions: all pointers in ff_ode_args are DEVICE pointers to contiguous fp32
+ * row-major arrays owned by the caller; launchers enqueue on the given hipStream_t and
+ * return immediately (0 = enqueued, <0 = error, nothing enqueued); no global state, safe
+ * to call from several host threads on different streams.
+ */
+#ifndef FLOWFUSION_AMD_H
+#define FLOWFUSION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FF_OK               0
+#define FF_ERR_BADARG      -1   /* null pointer / negative size / inconsistent plan        */
+#define FF_ERR_UNSUPPORTED -2   /* no gfx950 kernel instantiation covers this shape        */
+#define FF_ERR_HIP         -3   /* HIP runtime refused the launch (see ff_last_hip_error)  */
+
+#define FF_MAX_SLOTS   6        /* Runge-Kutta stage slots kept on chip                    */
+#define FF_ROW_HDR     32       /* 4-byte words in the header of one evaluation row        */
+
+/* mode flags for ff_ode_args.mode */
+#define FF_MODE_STATE      0    /* integrate the state only (32 samples per wavefront)     */
+#define FF_MODE_HUTCH      1    /* state + Hutchinson divergence e^T J e in forward mode
+                                   (16 samples + 16 tangent columns per wavefront)         */
+#define FF_MODE_EXACT      2    /* state + exact divergence tr J: `dim` unit tangents per
+                                   sample (reference default: diffusion.py:483-503,
+                                   flow.py:158-161)                                        */
+
+/* evaluation-row flag bits (word 3 of the row header) */
+#define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */
+#define FF_ROW_NOISE       2u   /* after the step update: y += gn * noise[noise_index]     */
+
+/*
+ * Kernel plan for one network shape: which compiled instantiation serves it and how its
+ * weights are tiled.  Filled by ff_mlp_plan; treat as opaque apart from reading.
+ */
+typedef struct ff_mlp_plan_t {
+    int32_t dim;         /* D  state dimension = network outputs                          */
+    int32_t cond_dim;    /* C  conditional inputs (0 = unconditional)                     */
+    int32_t n_hidden;    /* number of hidden (Linear+SiLU) layers, >= 1                   */
+    int32_t width;       /* common padded hidden width used on chip (multiple of 32)      */
+    int32_t dregs;       /* state registers per lane   = 4*ceil(D/8), padded to kernel    */
+    int32_t cregs;       /* conditional registers per lane                                */
+    int32_t kernel_id;   /* index into the compiled instantiation table                   */
+    int32_t reserved;
+} ff_mlp_plan_t;
+
+/* Arguments of one fused integration launch. */
+typedef struct ff_ode_args {
+    const float* x_in;       /* [batch, dim]  initial state                                */
+    float*       x_out;      /* [batch, dim]  final state                                  */
+    const float* cond;       /* [batch, cond_dim] or NULL                                  */
+    const float* probe;      /* [batch, dim]  Hutchinson probe e (FF_MODE_HUTCH) or NULL   */
+    float*       dlogp_out;  /* [batch]       integrated divergence (modes 1,2) or NULL    */
+    const float* noise;      /* [n_noise, batch, dim] standard normals (EM) or NULL        */
+    const float* wpack;      /* packed weights, ff_mlp_wpack_floats() floats               */
+    const float* etab;       /* [n_evals, FF_ROW_HDR + width] evaluation rows              */
+    const float* in_shift;   /* [dim] or NULL: y0 = (x_in - in_shift) / in_scale           */
+    const float* in_scale;   /* [dim] or NULL                                              */
+    const float* out_scale;  /* [dim] or NULL: x_out = y * out_scale + out_shift           */
+    const float* out_shift;  /* [dim] or NULL                                              */
+    uint32_t*    status;     /* device word, OR-ed with 1 if any final state is NaN; NULL ok */
+    int64_t      batch;      /* number of samples                                          */
+    int64_t      noise_stride; /* floats between consecutive noise slabs (>= batch*dim)    */
+    int32_t      n_evals;    /* rows in etab                                               */
+    int32_t      mode;       /* FF_MODE_*                                                  */
+} ff_ode_args;
+
+/* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */
+const char* ff_version(void);
+
+/* Number of compiled kernel instantiations, and a printable description of each. */
+int ff_kernel_count(void);
+const char* ff_kernel_name(int kernel_id);
+
+/*
+ * Choose the kernel instantiation for a network: `hidden_widths[n_hidden]` are the
+ * reference's `units` / `hidden_units` (diffusion.py:61-72, flow.py:64-71).  Widths are
+ * padded with zero rows/columns up to a compiled width; FF_ERR_UNSUPPORTED if none fits.
+ */
+int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                ff_mlp_plan_t* plan_out);
+
+/* Floats in the packed weight buffer of a plan. */
+size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan);
+
+/*
+ * Repack nn.Linear weights (HOST pointers, row-major [out_features, in_features]) into
+ * the MFMA operand order of the plan.  W[0] is the first layer with `in_features0`
+ * columns, of which columns [x_col0, x_col0+dim) multiply the state and
+ * [c_col0, c_col0+cond_dim) the conditional (reference column order: MLP =
+ * [time-embedding | x | cond] diffusion.py:109-113; flows = [x | t | cond]
+ * flow.py:112-115,583-586); its remaining columns and its bias are NOT packed -- the
+ * caller folds them into c1_e.  W[1..n_hidden-1] are hidden layers, W[n_hidden] the output
+ * layer.  b[0] is ignored (may be NULL).  `out` is a HOST buffer of
+ * ff_mlp_wpack_floats(plan) floats.
+ */
+int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
+                 const int* hidden_widths, int in_features0, int x_col0, int c_col0,
+                 float* out);
+
+/*
+ * Enqueue the fused integration on `hip_stream` (a hipStream_t; NULL = default stream).
+ */
+int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* args, void* hip_stream);
+
+/* Samples handled by one workgroup of a plan/mode (for sizing and roofline accounting). */
+int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode);
+
+/* hipError_t of the most recent failing launch on this thread (0 if none). */
+int ff_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWFUSION_AMD_H */
