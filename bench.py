@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Headline benchmark: samples/s of the fused probability-flow ODE sampler on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 16-dim VP-SDE score
+model, MLP 4x256 (embedding 8, no conditionals), 100-step RK4 (torchdiffeq's "rk4" = 3/8 rule, 400
+network evaluations per sample), batch 2^20 per GPU, random-init weights (seed 0), synthetic
+standard-normal base samples resident in HBM.  One "step" = one full solve of the batch.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, every rank solves its own 2^20-sample shard (weak scaling) and the
+shards meet in one RCCL all-gather per step, inside the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline`: the path is a dense fp32 contraction (1.3e6 FLOP per algorithmic HBM byte), so the
+bounding roofline is the fp32 MFMA peak; `achieved` = algorithmic FLOPs of one launch (2 x MACs of
+the Linear layers x 400 evaluations x batch) / the kernel's launch duration measured with HIP
+events on the launch stream.  `cpu_baseline`: the CPU oracle (unfused torch ops + Python stepping
+loop, i.e. the reference's CPU algorithm restated) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+DIM, UNITS, EMB = 16, [256, 256, 256, 256], 8
+N_STEPS = 100
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def mac_per_eval(dim, units, cond=0):
+    sizes = [dim + cond + EMB] + list(units) + [dim]
+    return sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+
+
+def build_model(device):
+    from flowfusion_amd.diffusion import MLP, VPSDE, ScoreModel
+    torch.manual_seed(0)
+    mlp = MLP(n_dimensions=DIM, n_conditionals=0, embedding_dimensions=EMB, units=UNITS)
+    return ScoreModel(mlp, VPSDE(), no_sigma=True).eval().to(device)
+
+
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(sm, batch_cpu, opts, budget_s=20.0):
+    """Oracle ("port") timed on the host: same workload on a bounded sample (chunks of 2048 samples
+    until `batch_cpu` samples or `budget_s` seconds, whichever comes first)."""
+    from oracle import flowfusion_oracle as O
+    sd = {k: v.detach().cpu() for k, v in sm.state_dict().items()}
+    so = O.ScoreOracle(O.mlp_params_from_state_dict(sd, "model."), O.VP(), no_sigma=True)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    z = torch.randn(batch_cpu, DIM)
+    so.sample_ode_from_base(z[:256], None, "rk4", {"step_size": opts["step_size"] * 10})   # warm-up
+    outs, done = [], 0
+    t0 = time.perf_counter()
+    while done < batch_cpu and (time.perf_counter() - t0 < budget_s or done == 0):
+        outs.append(so.sample_ode_from_base(z[done:done + 2048], None, "rk4", opts))
+        done += outs[-1].shape[0]
+    dt = time.perf_counter() - t0
+    return torch.cat(outs), z[:done], {
+        "value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": f"{done} samples x 100 RK4 steps (same model and grid, torch fp32 CPU oracle, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
+    ap.add_argument("--cpu-batch", type=int, default=16384, help="samples for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (there is no CPU path to time)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    sm = build_model(device)
+    eps = float(sm.sde.epsilon)
+    opts = {"step_size": (1.0 - eps) / N_STEPS}
+    B = args.batch
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    z = torch.randn(B, DIM, device=device, generator=gen)
+    gathered = torch.empty(world * B, DIM, device=device) if world > 1 else None
+
+    def step():
+        x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, x)
+        return x
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        x = step()
+    barrier()
+    # kernel-only durations: HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    net = sm._net()
+    table = sm._ode_table(torch.tensor([1.0, eps]), "rk4", opts, 0).to(device)
+    n_evals = table.shape[0]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # per-launch kernel time, measured separately so the event records do not sit in the timed region
+    for s, e in ev:
+        s.record()
+        net.integrate(z, table, 0)
+        e.record()
+    torch.cuda.synchronize(device)
+    kernel_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        print(f"[bench] timed region {elapsed:.3f} s, kernel avg {kernel_ms_avg:.1f} ms", file=sys.stderr, flush=True)
+        total = world * B * args.steps
+        flop_per_launch = 2.0 * mac_per_eval(DIM, UNITS) * n_evals * B
+        achieved = flop_per_launch / (kernel_ms_avg * 1e-3) / 1e12
+        alg_bytes = 2 * DIM * 4 * B
+        out = {
+            "metric": "samples/sec (whole node), 16-dim VP-SDE 100-step RK4",
+            "value": total / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 16-dim VP-SDE score model, MLP 4x256, 100-step RK4 "
+                                   "probability-flow ODE sampler (torchdiffeq rk4 = 3/8 rule, %d evals)" % n_evals,
+                       "batch_per_gpu": B, "global_batch": world * B, "state_dim": DIM, "hidden": UNITS,
+                       "sharding": f"batch x{world}, one RCCL all-gather per step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "mlp_ode_h256_d8_c0_t0", "kernel_ms_avg": kernel_ms_avg,
+                         "flop_per_launch": flop_per_launch,
+                         "algorithmic_hbm_bytes_per_launch": alg_bytes,
+                         "algorithmic_hbm_GBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9,
+                         "hbm_frac_of_8TBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
+        traffic_file = ROOT / "profiles" / "hbm_traffic.json"
+        if traffic_file.exists():
+            out["roofline"]["traffic"] = json.loads(traffic_file.read_text()).get("bytes_per_launch")
+        if args.cpu_batch > 0:
+            ref, zc, cb = cpu_baseline(sm, args.cpu_batch, opts)
+            out["cpu_baseline"] = cb
+            # parity of the timed configuration: GPU vs oracle on the same base samples
+            xg, _ = sm.sample_ode_from_base(zc.to(device), method="rk4", options=opts)
+            out["parity_vs_cpu_oracle"] = {
+                "max_abs_err_over_max_abs": float((xg.cpu() - ref).abs().max() / ref.abs().max()),
+                "n": int(zc.shape[0])}
+            # log_prob relative error (second half of BASELINE's metric), Hutchinson, 100-step RK4
+            from oracle import flowfusion_oracle as O
+            sd = {k: v.detach().cpu() for k, v in sm.state_dict().items()}
+            so = O.ScoreOracle(O.mlp_params_from_state_dict(sd, "model."), O.VP(), no_sigma=True)
+            sm.hutch = True
+            torch.manual_seed(99)
+            xq = torch.randn(128, DIM) * 0.9
+            lp = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
+            lp_ref = so.log_prob(xq, None, "rk4", opts, "hutch", sm.e.cpu())
+            out["log_prob_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,8 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
     x_out = torch.empty_like(x)
     dlogp = torch.zeros(B if mode != MODE_STATE else 0, dtype=torch.float32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if B == 0:                      # nothing to integrate (zero-size tensors have no storage to point at)
+        return x_out, dlogp, status
     a = OdeArgs()
     a.x_in = _chk(x, "x", dev)
     a.x_out = x_out.data_ptr()

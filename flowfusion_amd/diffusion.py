@@ -274,13 +274,21 @@ class ScoreModel(nn.Module):
         """Euler-Maruyama sampling of the reverse SDE; returns the last *mean* state, like the
         reference (diffusion.py:510-563).  Random numbers are drawn exactly as the reference draws
         them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
-        ``torch.manual_seed`` reproduces the reference's GPU stream."""
+        ``torch.manual_seed`` reproduces the reference's stream on that device."""
         batch, *dims = shape
-        net = self._net()
         dev = next(self.model.parameters()).device
         x = self.sde.prior(dims).sample([batch]).to(dev)
+        return self._sample_sde_from(x, lambda like: torch.randn_like(like), conditional, steps)
+
+    @torch.no_grad()
+    def _sample_sde_from(self, x, draw, conditional=None, steps=100):
+        """The Euler-Maruyama loop proper: ``x`` is the prior draw, ``draw(like)`` supplies the i-th
+        standard-normal slab (tests inject the reference's captured stream here)."""
+        net = self._net()
         if x.dim() != 2:
             raise NotImplementedError("sample_sde: only [batch, dim] states are supported")
+        dev = x.device
+        batch = x.shape[0]
         T = torch.as_tensor(self.sde.T, dtype=torch.float32).cpu()
         eps = self.sde.epsilon.detach().cpu()
         ts, dt = solvers.plan_euler_maruyama(T, eps, steps)
@@ -288,34 +296,28 @@ class ScoreModel(nn.Module):
         if n == 0:
             raise RuntimeError("sample_sde: T < epsilon, no step to take")
         a, b, c1, g = self._schedule(ts, "sde")
-        sqrt_mdt = (-dt) ** (1.0 / 2.0)
-        # rows: one evaluation per step; x_mean = x + f dt ; x = x_mean + g dw
+        gn = g * (-dt) ** (1.0 / 2.0)                 # g * sqrt(-dt)  (:554-558)
+        flags = torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32)
+        flags[-1] = solvers.FLAG_STEP_END             # the returned state is x_mean of the last step (:563)
+        cout = torch.zeros(n, 8)
+        cout[:, 0] = dt                               # x_mean = x + f dt  (:557)
         zeros8 = torch.zeros(n, 8)
-        cout = zeros8.clone()
-        cout[:, 0] = dt
-        plan = solvers.EvalPlan(t_eval=ts, sign=1.0, slot=torch.zeros(n, dtype=torch.int32),
-                                flags=torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32),
-                                cin=zeros8, cout=cout, n_steps=n)
-        plan.flags[-1] = solvers.FLAG_STEP_END            # the returned state is x_mean of the last step
-        gn = g * sqrt_mdt
-        # noise slabs are drawn per step, in order, on the device -- chunked to bound memory
-        per_step = batch * x.shape[1]
-        chunk = max(1, min(n, (1 << 29) // max(per_step, 1)))
-        start = 0
+        slot = torch.zeros(n, dtype=torch.int32)
+        # noise slabs are drawn per step, in order -- chunked over steps to bound memory
+        per_step = max(batch * x.shape[1], 1)
+        chunk = max(1, min(n, (1 << 29) // per_step))
         status_any = None
-        while start < n:
+        for start in range(0, n, chunk):
             stop = min(n, start + chunk)
             noise = torch.empty(stop - start, batch, x.shape[1], device=dev, dtype=torch.float32)
-            for i in range(stop - start):      # one draw per executed step, the last included (:554)
-                noise[i] = torch.randn_like(x)
-            sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=plan.slot[start:stop],
-                                   flags=plan.flags[start:stop], cin=plan.cin[start:stop],
-                                   cout=plan.cout[start:stop], n_steps=stop - start)
+            for i in range(stop - start):             # one draw per executed step, the last included (:554)
+                noise[i] = draw(x)
+            sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=slot[start:stop], flags=flags[start:stop],
+                                   cin=zeros8[start:stop], cout=cout[start:stop], n_steps=stop - start)
             table = solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
                                         gn=gn[start:stop], noise_idx=torch.arange(stop - start))
             x, _, status = net.integrate(x, table, MODE_STATE, cond=conditional, noise=noise)
             status_any = status if status_any is None else (status_any | status)
-            start = stop
         if int(status_any.item()) & 1:
             print("Diffusion is not stable, NaN were produced. Stopped sampling.")
         return x

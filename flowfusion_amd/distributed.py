@@ -1,0 +1,65 @@
+"""Multi-GPU execution of the sampling / log-density path: one process per GPU, batch sharding,
+one collective at the end.
+
+The reference is single-process (no torch.distributed anywhere in flowfusion/).  Samples are
+independent -- nothing on the path couples two rows of the batch -- so the batch axis is cut into
+contiguous, balanced shards, every rank integrates its shard with the fused kernel (weights and the
+evaluation table are a few MB and simply replicated), and the results meet in a single RCCL
+all-gather over xGMI (backend "nccl" is RCCL on ROCm).  No other collective is used.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of an n-row batch owned by `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n: int, world: int):
+    return [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+
+
+def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """All-gather the row shards produced under `shard_bounds` back into the full [n_total, ...]
+    tensor on every rank (one collective; ragged shards are padded to the largest)."""
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_total, world)
+    if world == 1:
+        return local
+    if len(set(sizes)) == 1:
+        out = local.new_empty((n_total,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    mx = max(sizes)
+    pad = local.new_zeros((mx,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    buf = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+def run_sharded(fn: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch.Tensor]], group=None,
+                gather: bool = True):
+    """Apply `fn(*row_slices)` to this rank's shard of every [B, ...] input and (optionally) gather.
+
+    Every rank passes the same full-batch `inputs` (or `None` entries); rank r computes rows
+    ``shard_bounds(B, world, r)``.  With ``gather=False`` the local result is returned together
+    with its bounds, for consumers that keep the data distributed.
+    """
+    n = next(t.shape[0] for t in inputs if t is not None)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(n, world, rank)
+    local = fn(*[None if t is None else t[lo:hi].contiguous() for t in inputs])
+    if not gather:
+        return local, (lo, hi)
+    if isinstance(local, (tuple, list)):
+        return type(local)(gather_rows(t, n, group) if torch.is_tensor(t) else t for t in local)
+    return gather_rows(local, n, group)

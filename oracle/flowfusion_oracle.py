@@ -1,0 +1,440 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A plain-torch, CPU restatement of the reference algorithm for the hot path (flowfusion's
+probability-flow ODE / reverse-SDE sampling and log-density evaluation).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
+product (``flowfusion_amd/``) never does.
+
+It deliberately keeps the reference's *unfused* op sequence (embed -> concat -> Linear/SiLU stack ->
+score scaling -> drift, autograd for the divergence, a Python stepping loop), so it doubles as the
+"port" CPU baseline.  Every function cites the reference lines it follows
+(``diffusion.py`` = /root/reference/flowfusion/diffusion.py, ``flow.py`` likewise).
+
+Pinning:
+  * network / SDE schedules / RHS / divergence / Euler-Maruyama loop: pinned against golden vectors
+    produced by the reference's own code (tests/golden/*.npz, made by tests/golden/make_golden.py).
+  * ODE time stepping: the reference delegates it to torchdiffeq (>=0.2.5,<0.3.0,
+    pyproject.toml:12), which is NOT in /root/reference and not installed offline.  ``odeint_fixed``
+    restates torchdiffeq's published fixed-grid algorithm from memory of that package --
+    PARITY UNPINNED for the stepper itself.  It is anchored by (a) hybrid vectors: this stepper
+    driving the reference's own RHS (tests/golden), (b) known-answer tests with analytic scores
+    (convergence order), see tests/test_oracle_*.py.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+# =================================================================================================
+# parameters
+# =================================================================================================
+@dataclass
+class MLPParams:
+    """Plain tensors of the reference's score network (state_dict keys model.W, model.pi,
+    model.NN.{i}.weight/bias)."""
+    W: torch.Tensor                 # [E/2] embedding frequencies
+    pi: torch.Tensor                # 0-dim
+    weights: List[torch.Tensor]     # [out, in] per Linear
+    biases: List[torch.Tensor]
+
+    def to(self, dtype):
+        return MLPParams(self.W.to(dtype), self.pi.to(dtype), [w.to(dtype) for w in self.weights],
+                         [b.to(dtype) for b in self.biases])
+
+
+def mlp_params_from_state_dict(sd, prefix="model.") -> MLPParams:
+    n = 0
+    while f"{prefix}NN.{n}.weight" in sd:
+        n += 1
+    return MLPParams(W=sd[f"{prefix}W"].detach().clone(), pi=sd[f"{prefix}pi"].detach().clone(),
+                     weights=[sd[f"{prefix}NN.{i}.weight"].detach().clone() for i in range(n)],
+                     biases=[sd[f"{prefix}NN.{i}.bias"].detach().clone() for i in range(n)])
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+def mlp_forward(p: MLPParams, t, x, conditional=None):
+    """diffusion.py:82-121 -- concat conditional, broadcast scalar t, Gaussian-Fourier features
+    ``t*W*2*pi`` (in that order), ``[sin, cos, x]``, Linear/SiLU stack, final Linear."""
+    if conditional is not None:
+        x = torch.cat([x, conditional], dim=1)                      # :101-102
+    if t.dim() == 0:
+        t = t * torch.ones(x.shape[:-1], dtype=x.dtype)             # :105-106
+    t_proj = t[:, None] * p.W[None, :] * 2 * p.pi                   # :109
+    h = torch.cat([torch.sin(t_proj), torch.cos(t_proj), x], dim=1)  # :110-113
+    for w, b in zip(p.weights[:-1], p.biases[:-1]):                  # :116-118
+        h = silu(torch.nn.functional.linear(h, w, b))
+    return torch.nn.functional.linear(h, p.weights[-1], p.biases[-1])   # :119
+
+
+# =================================================================================================
+# SDE schedules
+# =================================================================================================
+class VP:
+    """diffusion.py:1006-1180."""
+    kind = "vp"
+
+    def __init__(self, beta_min=0.1, beta_max=20, T=1.0, epsilon=1e-3, dtype=torch.float32):
+        self.beta_min, self.beta_max, self.T = beta_min, beta_max, T
+        self.epsilon = torch.tensor(epsilon, dtype=torch.float32).to(dtype)
+        self.dtype = dtype
+
+    def beta(self, t):                                               # :1061
+        return self.beta_min + (self.beta_max - self.beta_min) * (t / self.T)
+
+    def marginal_prob_scalars(self, t):                              # :1152-1156
+        log_coeff = 0.5 * (self.beta_max - self.beta_min) * t ** 2 / self.T + self.beta_min * t
+        return torch.exp(-0.5 * log_coeff), torch.sqrt(1.0 - torch.exp(-log_coeff))
+
+    def sigma(self, t):                                              # :1077
+        return self.marginal_prob_scalars(t)[1]
+
+    def diffusion(self, t, x):                                       # :1111-1112
+        return torch.sqrt(self.beta(t)).view(-1, *[1] * (x.dim() - 1))
+
+    def drift(self, t, x):                                           # :1130-1131
+        return -0.5 * self.beta(t).view(-1, *[1] * (x.dim() - 1)) * x
+
+    def prior_scale(self):                                           # :1093  Normal(0, 1)
+        return torch.tensor(1.0, dtype=self.dtype)
+
+    base_scale = None                                                # ODE base is not rescaled (:607-608)
+
+    def T_value(self):
+        return torch.tensor(self.T, dtype=self.dtype)
+
+
+class SubVP(VP):
+    """diffusion.py:1183-1366."""
+    kind = "subvp"
+
+    def diffusion(self, t, x):                                       # :1287-1297
+        return torch.sqrt(
+            self.beta(t) * (1.0 - torch.exp(-2 * self.beta_min * t - (self.beta_max - self.beta_min) * t ** 2 / self.T))
+        ).view(-1, *[1] * (x.dim() - 1))
+
+    def marginal_prob_scalars(self, t):                              # :1337-1342
+        log_coeff = 0.5 * (self.beta_max - self.beta_min) * t ** 2 / self.T + self.beta_min * t
+        return torch.exp(-0.5 * log_coeff), 1.0 - torch.exp(-log_coeff)
+
+
+class VE:
+    """diffusion.py:818-1003 (all four scalars are fp32 buffers there)."""
+    kind = "ve"
+
+    def __init__(self, sigma_min=1e-2, sigma_max=10.0, T=1.0, epsilon=1e-5, dtype=torch.float32):
+        f = lambda v: torch.tensor(v, dtype=torch.float32).to(dtype)
+        self.T, self.epsilon, self.sigma_min, self.sigma_max = f(T), f(epsilon), f(sigma_min), f(sigma_max)
+        self.dtype = dtype
+
+    def sigma(self, t):                                              # :866
+        return self.sigma_min * (self.sigma_max / self.sigma_min) ** (t / self.T)
+
+    def diffusion(self, t, x):                                       # :884-887
+        return self.sigma(t).view(-1, *[1] * (x.dim() - 1)) * torch.sqrt(
+            2 * (torch.log(self.sigma_max) - torch.log(self.sigma_min)) / self.T)
+
+    def drift(self, t, x):                                           # :905
+        return torch.zeros_like(x)
+
+    def prior_scale(self):                                           # :1003  Normal(0, sigma_max)
+        return self.sigma_max
+
+    @property
+    def base_scale(self):                                            # :605-606
+        return self.sigma_max
+
+    def T_value(self):
+        return self.T
+
+
+def normal_log_prob(x, scale):
+    """torch.distributions.Normal(0, scale).log_prob(x) written out (used at diffusion.py:814)."""
+    scale = torch.as_tensor(scale, dtype=x.dtype)
+    var = scale ** 2
+    return -(x ** 2) / (2 * var) - torch.log(scale) - math.log(math.sqrt(2 * math.pi))
+
+
+# =================================================================================================
+# score model pieces
+# =================================================================================================
+class ScoreOracle:
+    """diffusion.py:124-815 restated over plain tensors."""
+
+    def __init__(self, params: MLPParams, sde, no_sigma=False, dtype=torch.float32):
+        self.p = params.to(dtype)
+        self.sde = sde
+        self.no_sigma = no_sigma
+        self.dtype = dtype
+
+    def score(self, t, x, conditional=None):                         # :233-238
+        out = mlp_forward(self.p, t, x, conditional)
+        if self.no_sigma:
+            return out
+        return out / self.sde.sigma(t).view(-1, *[1] * len(x.shape[1:]))
+
+    def ode_drift(self, t, x, conditional=None):                     # :276-279
+        f = self.sde.drift(t, x)
+        g = self.sde.diffusion(t, x)
+        return f - 0.5 * g ** 2 * self.score(t, x, conditional=conditional)
+
+    def rhs(self, t, states, conditional=None, divergence: Optional[str] = None, e=None):
+        """diffusion.py:281-334, 483-508: ``states=(x,)`` -> xdot ; with ``divergence`` in
+        {"hutch","exact"} ``states=(x, dlogp)`` -> (xdot, div[B,1])."""
+        x = states[0]
+        if divergence is None:
+            with torch.no_grad():
+                return (self.ode_drift(t, x, conditional),)
+        with torch.enable_grad():
+            x = x.detach().requires_grad_(True)                      # :319
+            x_dot = self.ode_drift(t, x, conditional)                # :323
+            if divergence == "hutch":                                # :329-334
+                div = torch.sum(torch.autograd.grad(x_dot, x, e, retain_graph=False)[0] * e, dim=1)
+            elif divergence == "exact":                              # :483-503 (trace of the Jacobian)
+                div = torch.zeros(x.shape[0], dtype=x.dtype)
+                for i in range(x.shape[1]):
+                    div = div + torch.autograd.grad(x_dot[:, i].sum(), x, retain_graph=True)[0][:, i]
+            else:
+                raise ValueError(divergence)
+        return x_dot.detach(), div.detach().view(x.shape[0], 1)       # :505-506
+
+    # ---- solves ------------------------------------------------------------------------------------
+    def sample_ode_from_base(self, base, conditional=None, method="rk4", options=None):
+        """diffusion.py:566-640 (returns just the samples)."""
+        z = base * self.sde.base_scale if self.sde.base_scale is not None else base     # :605-608
+        times = torch.stack([torch.tensor(1.0, dtype=torch.float32), self.sde.epsilon.to(torch.float32)]).to(self.dtype)  # :611
+        func = lambda t, y: self.rhs(t, y, conditional, None)
+        (traj,) = odeint_fixed(func, (z,), times, method, options)
+        return traj
+
+    def solve_odes_forward(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None):
+        """diffusion.py:642-754 -> (xT, delta_logp[B,1])."""
+        dlogp = torch.zeros(x0.shape[0], 1, dtype=x0.dtype)         # :724
+        times = torch.stack([self.sde.epsilon.to(torch.float32), torch.tensor(1.0, dtype=torch.float32)]).to(self.dtype)  # :727
+        func = lambda t, y: self.rhs(t, y, conditional, divergence, e)
+        return odeint_fixed(func, (x0, dlogp), times, method, options)
+
+    def log_prob(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None):
+        """diffusion.py:756-815 -> [B,1]."""
+        xT, lp = self.solve_odes_forward(x0, conditional, method, options, divergence, e)
+        return lp + torch.sum(normal_log_prob(xT, self.sde.prior_scale()), dim=1, keepdim=True)   # :814
+
+    def sample_sde(self, x_prior, noise: Sequence[torch.Tensor], conditional=None, steps=100):
+        """diffusion.py:510-563 with the random draws supplied by the caller: ``x_prior`` is the
+        prior sample (:532-536), ``noise[i]`` the i-th ``randn_like`` (:554).  Returns x_mean (:563)."""
+        x = x_prior
+        batch = x.shape[0]
+        dt = -(self.sde.T_value() - self.sde.epsilon) / steps         # :539
+        t = torch.ones(batch, dtype=self.dtype) * self.sde.T_value()  # :540
+        x_mean = x
+        with torch.no_grad():
+            for i in range(steps):                                    # :543
+                if t[0] < self.sde.epsilon:                           # :548-551
+                    break
+                g = self.sde.diffusion(t, x)                          # :552
+                f = self.sde.drift(t, x) - g ** 2 * self.score(t, x, conditional=conditional)   # :553
+                dw = noise[i] * (-dt) ** (1.0 / 2.0)                  # :554-556
+                x_mean = x + f * dt                                   # :557
+                x = x_mean + g * dw                                   # :558
+                t = t + dt                                            # :559
+                if torch.any(torch.isnan(x)):                         # :560-562
+                    break
+        return x_mean
+
+
+# =================================================================================================
+# fixed-grid ODE stepping (restatement of torchdiffeq's algorithm -- see the module docstring)
+# =================================================================================================
+_ONE_THIRD = 1.0 / 3.0
+_TWO_THIRDS = 2.0 / 3.0
+
+
+def _axpy(y, a, k):
+    return tuple(yi + a * ki for yi, ki in zip(y, k))
+
+
+def _step_euler(func, t0, dt, t1, y0):
+    f0 = func(t0, y0)
+    return tuple(dt * f for f in f0)
+
+
+def _step_midpoint(func, t0, dt, t1, y0):
+    half_dt = 0.5 * dt
+    f0 = func(t0, y0)
+    y_mid = _axpy(y0, half_dt, f0)
+    return tuple(dt * f for f in func(t0 + half_dt, y_mid))
+
+
+def _step_heun3(func, t0, dt, t1, y0):
+    k1 = func(t0, y0)
+    k2 = func(t0 + dt * _ONE_THIRD, tuple(y + dt * a * _ONE_THIRD for y, a in zip(y0, k1)))
+    k3 = func(t0 + dt * _TWO_THIRDS, tuple(y + dt * (a * 0.0 + b * _TWO_THIRDS) for y, a, b in zip(y0, k1, k2)))
+    return tuple(dt * (a * 0.25 + b * 0.0 + c * 0.75) for a, b, c in zip(k1, k2, k3))
+
+
+def _step_rk4_38(func, t0, dt, t1, y0):
+    """torchdiffeq's ``rk4`` = 3/8 rule ("rk4_alt_step_func")."""
+    k1 = func(t0, y0)
+    k2 = func(t0 + dt * _ONE_THIRD, tuple(y + dt * a * _ONE_THIRD for y, a in zip(y0, k1)))
+    k3 = func(t0 + dt * _TWO_THIRDS, tuple(y + dt * (b - a * _ONE_THIRD) for y, a, b in zip(y0, k1, k2)))
+    k4 = func(t1, tuple(y + dt * (a - b + c) for y, a, b, c in zip(y0, k1, k2, k3)))
+    return tuple((a + 3 * (b + c) + d) * dt * 0.125 for a, b, c, d in zip(k1, k2, k3, k4))
+
+
+def _step_rk4_classic(func, t0, dt, t1, y0):
+    half_dt = dt * 0.5
+    k1 = func(t0, y0)
+    k2 = func(t0 + half_dt, _axpy(y0, half_dt, k1))
+    k3 = func(t0 + half_dt, _axpy(y0, half_dt, k2))
+    k4 = func(t1, _axpy(y0, dt, k3))
+    return tuple((a + 2 * (b + c) + d) * dt * (1.0 / 6.0) for a, b, c, d in zip(k1, k2, k3, k4))
+
+
+_DP_C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0)
+_DP_A = ((), (1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9),
+         (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+         (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656))
+_DP_B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
+
+
+def _step_dopri5_fixed(func, t0, dt, t1, y0):
+    """Dormand-Prince 5th-order weights on a fixed step (extension; not a torchdiffeq method name)."""
+    ks = []
+    for i in range(6):
+        yi = y0
+        for j, a in enumerate(_DP_A[i]):
+            yi = _axpy(yi, dt * a, ks[j])
+        ti = t1 if i == 5 else (t0 if i == 0 else t0 + dt * _DP_C[i])
+        ks.append(func(ti, yi))
+    out = tuple(torch.zeros_like(y) for y in y0)
+    for j, b in enumerate(_DP_B):
+        out = _axpy(out, dt * b, ks[j])
+    return out
+
+
+_STEPPERS = {"euler": _step_euler, "midpoint": _step_midpoint, "heun3": _step_heun3, "rk4": _step_rk4_38,
+             "rk4_classic": _step_rk4_classic, "dopri5_fixed": _step_dopri5_fixed}
+
+
+def grid_from_step_size(t, step_size):
+    start_time, end_time = t[0], t[-1]
+    niters = torch.ceil((end_time - start_time) / step_size + 1).item()
+    t_infer = torch.arange(0, niters, dtype=t.dtype) * step_size + start_time
+    t_infer[-1] = t[-1]
+    return t_infer
+
+
+def odeint_fixed(func: Callable, y0: Tuple[torch.Tensor, ...], t: torch.Tensor, method="rk4", options=None):
+    """Integrate ``dy/dt = func(t, y)`` from ``t[0]`` to ``t[-1]`` on a fixed grid; returns the tuple
+    of states at ``t[-1]``.
+
+    Restates torchdiffeq.odeint for ``method`` in euler/midpoint/heun3/rk4: decreasing ``t`` is solved
+    as ``-t`` with ``func`` negated; with ``options["step_size"]`` the grid is
+    ``arange(ceil((t1-t0)/h + 1))*h + t0`` with its last point set to ``t1``, otherwise the grid is
+    ``t`` itself (a single step); tuple states advance component-wise (torchdiffeq flattens them
+    into one vector, which is the same arithmetic).
+    """
+    options = dict(options or {})
+    step_size = options.get("step_size", None)
+    step = _STEPPERS[method]
+    if bool(t[0] > t[-1]):
+        t = -t
+        base = func
+        func = lambda tt, yy: tuple(-f for f in base(-tt, yy))
+    grid = t if step_size is None else grid_from_step_size(t, step_size)
+    y = tuple(y0)
+    for t0, t1 in zip(grid[:-1], grid[1:]):
+        dt = t1 - t0
+        dy = step(func, t0, dt, t1, y)
+        y = tuple(a + b for a, b in zip(y, dy))
+    return y
+
+
+# =================================================================================================
+# flows  (flow.py)
+# =================================================================================================
+@dataclass
+class FlowParams:
+    """state_dict tensors of ODEFlow / ConditionalODEFlow (layers.{0,2,..}.weight/bias, target_*,
+    conditional_*)."""
+    weights: List[torch.Tensor]
+    biases: List[torch.Tensor]
+    target_shift: torch.Tensor
+    target_scale: torch.Tensor
+    conditional_shift: Optional[torch.Tensor] = None
+    conditional_scale: Optional[torch.Tensor] = None
+
+    def to(self, dtype):
+        f = lambda v: None if v is None else v.to(dtype)
+        return FlowParams([w.to(dtype) for w in self.weights], [b.to(dtype) for b in self.biases],
+                          f(self.target_shift), f(self.target_scale), f(self.conditional_shift),
+                          f(self.conditional_scale))
+
+
+def flow_params_from_state_dict(sd) -> FlowParams:
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("layers.") and k.endswith(".weight")})
+    return FlowParams(weights=[sd[f"layers.{i}.weight"].detach().clone() for i in idx],
+                      biases=[sd[f"layers.{i}.bias"].detach().clone() for i in idx],
+                      target_shift=sd["target_shift"].detach().clone(), target_scale=sd["target_scale"].detach().clone(),
+                      conditional_shift=sd["conditional_shift"].detach().clone() if "conditional_shift" in sd else None,
+                      conditional_scale=sd["conditional_scale"].detach().clone() if "conditional_scale" in sd else None)
+
+
+class FlowOracle:
+    """flow.py:9-438 (unconditional) and :441-941 (conditional) restated over plain tensors."""
+
+    def __init__(self, params: FlowParams, dtype=torch.float32):
+        self.p = params.to(dtype)
+        self.dtype = dtype
+        self.twopi = torch.tensor(2.0 * 3.14159265358979323846, dtype=torch.float32).to(dtype)   # flow.py:77
+
+    def velocity(self, inputs):                                       # nn.Sequential, flow.py:68-74
+        h = inputs
+        for w, b in zip(self.p.weights[:-1], self.p.biases[:-1]):
+            h = silu(torch.nn.functional.linear(h, w, b))
+        return torch.nn.functional.linear(h, self.p.weights[-1], self.p.biases[-1])
+
+    def dynamics(self, t, x, conditional=None):
+        """flow.py:112-118 / :580-589: inputs = [x, t, (cond - shift)/scale]."""
+        cols = [x, t.view(-1, 1).expand(x.shape[0], 1)]
+        if conditional is not None:
+            cols.append((conditional - self.p.conditional_shift) / self.p.conditional_scale)
+        return self.velocity(torch.cat(cols, dim=1))
+
+    def dynamics_with_jacobian(self, t, x, conditional=None):
+        """flow.py:149-161 / :630-644: exact divergence, one autograd call per dimension."""
+        with torch.enable_grad():
+            x = x.detach().requires_grad_(True)
+            dxdt = self.dynamics(t, x, conditional)
+            div = torch.zeros(x.shape[0], 1, dtype=x.dtype)
+            for i in range(x.shape[-1]):
+                div = div + torch.autograd.grad(dxdt[:, i].sum(), x, retain_graph=True)[0][:, i].unsqueeze(1)
+        return dxdt.detach(), div.detach()
+
+    def sample(self, xT, conditional=None, method="rk4", options=None):
+        """flow.py:282-305 / :775-798: integrate t: 1 -> 0, then ``* target_scale + target_shift``."""
+        times = torch.tensor([1.0, 0.0], dtype=torch.float32).to(self.dtype)
+        with torch.no_grad():
+            func = lambda t, y: (self.dynamics(t, y[0], conditional),)
+            (x0,) = odeint_fixed(func, (xT,), times, method, options)
+        return x0 * self.p.target_scale + self.p.target_shift
+
+    def solve_ode_forward(self, x, conditional=None, method="rk4", options=None):
+        """flow.py:347-384 / :844-883 -> (xT, log_jacobian[B,1])."""
+        logj = torch.zeros(x.shape[0], 1, dtype=x.dtype)
+        times = torch.tensor([0.0, 1.0], dtype=torch.float32).to(self.dtype)
+        func = lambda t, y: self.dynamics_with_jacobian(t, y[0], conditional)
+        return odeint_fixed(func, (x, logj), times, method, options)
+
+    def log_prob(self, x, conditional=None, method="rk4", options=None):
+        """flow.py:420-438 / :922-941 -> [B]."""
+        x = (x - self.p.target_shift) / self.p.target_scale
+        xT, logj = self.solve_ode_forward(x, conditional, method, options)
+        lp = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
+        return lp + logj.squeeze(1) - torch.sum(torch.log(self.p.target_scale))

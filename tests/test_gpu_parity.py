@@ -1,0 +1,291 @@
+"""GPU tier (`-m gpu`, runs on a real MI355X): the HIP path, called through the product classes and
+hence through the C ABI of libflowfusion_amd.so, against
+
+  * the committed golden vectors (reference right-hand sides x restated stepper; reference
+    sample_sde output with its captured random stream),
+  * the CPU oracle on the same seeded inputs at sizes it finishes in seconds,
+  * size-independent properties at BASELINE.json's full batch (2^20): batch-shape invariance,
+    run-to-run determinism, ODE reversibility (sample then integrate back), probe sign symmetry.
+
+Tolerances (fp32 path): states within 1e-4 of the largest reference magnitude (the networks are
+random-init, so trajectories grow to O(10^2..10^3)); log-densities within 1e-4 relative -- the bar
+BASELINE.json's north_star states ("matching reference log_prob to 1e-4 rel").
+"""
+import pytest
+import torch
+
+from tests._util import (flow_model, flow_oracle, golden_names, load_golden, max_rel, score_model, score_oracle)
+
+pytestmark = pytest.mark.gpu
+
+STATE_TOL = 1e-4       # relative to max |reference state|
+LOGP_TOL = 1e-4        # relative (north_star)
+DEV = "cuda"
+
+
+def _state_err(got, exp):
+    return max_rel(got.cpu(), exp, floor=exp.abs().max().item())
+
+
+def _logp_err(got, exp):
+    return max_rel(got.cpu(), exp, floor=1.0)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built_library):
+    assert torch.cuda.is_available(), "the gpu tier needs a GPU"
+
+
+# ---- golden vectors --------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("hybrid_score_"))
+def test_score_model_against_golden(name):
+    meta, a = load_golden(name)
+    sm = score_model(meta, a, DEV)
+    cond = a.get("cond")
+    cond_d = None if cond is None else cond.to(DEV)
+    for run in meta["runs"]:
+        m, opts = run["method"], {"step_size": run["step_size"]}
+        x0, empty = sm.sample_ode_from_base(a["base"].to(DEV), conditional=cond_d, method=m, options=opts)
+        assert empty == [] and x0.shape == a["base"].shape
+        assert _state_err(x0, a[f"sample_{m}"]) < STATE_TOL, (name, m)
+        # Hutchinson log-density with the fixture's probe
+        sm.hutch = True
+        xd = a[f"x_data_{m}"].to(DEV)
+        tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), m, opts, 1)
+        xT, dlp, _ = sm._net().integrate(xd, tab, 1, cond=cond_d, probe=a[f"e_{m}"].to(DEV))
+        lp = dlp.view(-1, 1) + sm.sde.prior(xT.shape).log_prob(xT).sum(1, keepdim=True)
+        assert _logp_err(lp, a[f"lp_hutch_{m}"]) < LOGP_TOL, (name, m)
+        assert _state_err(xT, a[f"xT_{m}"]) < STATE_TOL
+        # exact trace through the public API (the reference's default divergence)
+        sm.hutch = False
+        if meta["D"] + 1 <= 32:
+            lp = sm.log_prob(xd, conditional=cond_d, method=m, options=opts)
+            assert lp.shape == (xd.shape[0], 1)
+            assert _logp_err(lp, a[f"lp_exact_{m}"]) < LOGP_TOL, (name, m)
+
+
+@pytest.mark.parametrize("name", golden_names("hybrid_flow") + golden_names("hybrid_cflow"))
+def test_flows_against_golden(name):
+    meta, a = load_golden(name)
+    f = flow_model(meta, a, DEV)
+    cond = a.get("cond")
+    args = () if cond is None else (cond.to(DEV),)
+    for run in meta["runs"]:
+        m, opts = run["method"], {"step_size": run["step_size"]}
+        x0 = f.sample(a["xT"].to(DEV), *args, method=m, options=opts)
+        assert _state_err(x0, a[f"sample_{m}"]) < STATE_TOL, (name, m)
+        lp = f.log_prob(a[f"x_data_{m}"].to(DEV), *args, method=m, options=opts)
+        assert lp.shape == (a["xT"].shape[0],)
+        assert _logp_err(lp, a[f"logprob_{m}"]) < LOGP_TOL, (name, m)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("sde_") if n != "sde_schedules"])
+def test_sample_sde_against_reference_stream(name):
+    """Feed the reference's captured draws: must reproduce the reference's sample_sde output."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a, DEV)
+    cond = a.get("cond")
+    draws = iter(a["noise"].to(DEV))
+    x = sm._sample_sde_from(a["x_prior"].to(DEV), lambda like: next(draws),
+                            None if cond is None else cond.to(DEV), steps=meta["steps"])
+    assert _state_err(x, a["out"]) < STATE_TOL
+
+
+# ---- oracle on seeded inputs ---------------------------------------------------------------------------
+def _seeded_score_model(D, C, units, sde_name, no_sigma, seed):
+    from flowfusion_amd import diffusion as Dm
+    torch.manual_seed(seed)
+    m = Dm.MLP(n_dimensions=D, n_conditionals=C, embedding_dimensions=8, units=units)
+    sde = getattr(Dm, sde_name)()
+    sm = Dm.ScoreModel(m, sde, no_sigma=no_sigma).eval()
+    meta = dict(D=D, C=C, E=8, units=units, sde=sde_name, sde_kw={}, no_sigma=no_sigma)
+    arrays = {k: v.detach().clone() for k, v in sm.state_dict().items()}
+    return sm.to(DEV), score_oracle(meta, arrays), score_oracle(meta, arrays, torch.float64)
+
+
+CONFIGS = {
+    # BASELINE.json configs restated at oracle-friendly batch sizes
+    "c1_2d_ve_3x128_euler50": (2, 0, [128] * 3, "VESDE", False, "euler", 50, 1000),
+    "c2_16d_vp_4x256_rk4_100": (16, 0, [256] * 4, "VPSDE", True, "rk4", 100, 777),
+    "c5_32d_c8_ve_4x256": (32, 8, [256] * 4, "VESDE", False, "rk4", 25, 300),
+    "ragged_5d_c3": (5, 3, [64, 100], "SUBVPSDE", False, "midpoint", 30, 129),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_sampling_against_oracle(name):
+    D, C, units, sde_name, no_sigma, method, nsteps, B = CONFIGS[name]
+    sm, so32, so64 = _seeded_score_model(D, C, units, sde_name, no_sigma, 11)
+    torch.manual_seed(1234)
+    base = torch.randn(B, D)
+    cond = torch.randn(B, C) if C else None
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+    got, _ = sm.sample_ode_from_base(base.to(DEV), conditional=None if cond is None else cond.to(DEV),
+                                     method=method, options=opts)
+    ref32 = so32.sample_ode_from_base(base, cond, method, opts)
+    ref64 = so64.sample_ode_from_base(base.double(), None if cond is None else cond.double(), method, opts)
+    e_gpu, e_cpu = _state_err(got, ref64.float()), _state_err(ref32, ref64.float())
+    assert _state_err(got, ref32) < STATE_TOL, (name, e_gpu, e_cpu)
+    assert e_gpu < STATE_TOL, (name, e_gpu, e_cpu)       # both fp32 paths sit within tolerance of fp64
+
+
+@pytest.mark.parametrize("name", ["c2_16d_vp_4x256_rk4_100", "c5_32d_c8_ve_4x256", "ragged_5d_c3"])
+def test_hutchinson_log_prob_against_oracle(name):
+    D, C, units, sde_name, no_sigma, method, nsteps, B = CONFIGS[name]
+    B = min(B, 256)
+    sm, so32, so64 = _seeded_score_model(D, C, units, sde_name, no_sigma, 12)
+    sm.hutch = True
+    torch.manual_seed(4321)
+    x0 = torch.randn(B, D) * 0.8 + 0.3
+    cond = torch.randn(B, C) if C else None
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+    torch.manual_seed(99)                                 # the probe is drawn on the CPU, like the reference
+    lp = sm.log_prob(x0.to(DEV), conditional=None if cond is None else cond.to(DEV), method=method, options=opts)
+    e = sm.e.cpu()
+    torch.manual_seed(99)
+    assert torch.equal(e, torch.sign(torch.randn(x0.shape)))   # same stream as diffusion.py:701
+    ref32 = so32.log_prob(x0, cond, method, opts, "hutch", e)
+    ref64 = so64.log_prob(x0.double(), None if cond is None else cond.double(), method, opts, "hutch", e.double())
+    assert lp.shape == (B, 1)
+    assert _logp_err(lp, ref32) < LOGP_TOL, name
+    assert _logp_err(lp, ref64.float()) < LOGP_TOL, name
+
+
+def test_exact_trace_log_prob_against_oracle():
+    sm, so32, so64 = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 13)
+    torch.manual_seed(5)
+    x0 = torch.randn(37, 16)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 20}
+    lp = sm.log_prob(x0.to(DEV), method="rk4", options=opts)          # hutchinson=False -> exact trace
+    ref = so64.log_prob(x0.double(), None, "rk4", opts, "exact")
+    assert _logp_err(lp, ref.float()) < LOGP_TOL
+
+
+def test_sample_sde_stream_and_oracle():
+    """Public sample_sde: same seed => same result; equals the oracle fed with the same device draws."""
+    sm, so32, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 14)
+    B, steps = 500, 20
+    torch.manual_seed(7)
+    a = sm.sample_sde((B, 16), steps=steps)
+    torch.manual_seed(7)
+    b = sm.sample_sde((B, 16), steps=steps)
+    assert torch.equal(a, b)
+    torch.manual_seed(7)
+    prior = sm.sde.prior([16]).sample([B]).to(DEV)
+    noise = [torch.randn_like(prior).cpu() for _ in range(steps)]
+    ref = so32.sample_sde(prior.cpu(), noise, None, steps=steps)
+    assert _state_err(a, ref) < STATE_TOL
+
+
+def test_flow_against_oracle_and_conditional():
+    from flowfusion_amd import flow as Fm
+    torch.manual_seed(21)
+    f = Fm.ConditionalODEFlow(target_dimension=16, conditional_dimension=6, hidden_units=[256, 256, 256],
+                              target_shift=torch.randn(16), target_scale=torch.rand(16) + 0.5,
+                              conditional_shift=torch.randn(6), conditional_scale=torch.rand(6) + 0.5).eval()
+    fo = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()})
+    fo64 = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()}, torch.float64)
+    f = f.to(DEV)
+    B = 200
+    xT, cond = torch.randn(B, 16), torch.randn(B, 6) * 2
+    opts = {"step_size": 1.0 / 40}
+    got = f.sample(xT.to(DEV), cond.to(DEV), method="rk4", options=opts)
+    assert _state_err(got, fo.sample(xT, cond, "rk4", opts)) < STATE_TOL
+    got = f.sample(xT.to(DEV), cond.to(DEV), method="dopri5_fixed", options=opts)      # 6-stage scheme
+    assert _state_err(got, fo64.sample(xT.double(), cond.double(), "dopri5_fixed", opts).float()) < STATE_TOL
+    x = xT[:48] * f.target_scale.cpu() + f.target_shift.cpu()
+    lp = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)
+    ref = fo64.log_prob(x.double(), cond[:48].double(), "rk4", opts)
+    assert _logp_err(lp, ref.float()) < LOGP_TOL
+
+
+# ---- edge cases ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 31, 32, 127, 128, 129, 1000])
+def test_ragged_batches(B):
+    sm, so32, _ = _seeded_score_model(16, 0, [64, 64], "VPSDE", True, 15)
+    torch.manual_seed(B)
+    base = torch.randn(B, 16)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 8}
+    got, _ = sm.sample_ode_from_base(base.to(DEV), method="rk4", options=opts)
+    assert _state_err(got, so32.sample_ode_from_base(base, None, "rk4", opts)) < STATE_TOL
+    sm.hutch = True
+    lp = sm.log_prob(base.to(DEV), method="euler", options=opts)
+    assert _logp_err(lp, so32.log_prob(base, None, "euler", opts, "hutch", sm.e.cpu())) < LOGP_TOL
+
+
+def test_empty_batch_and_nan_flag():
+    sm, _, _ = _seeded_score_model(16, 0, [64, 64], "VPSDE", True, 16)
+    opts = {"step_size": 0.25}
+    out, _ = sm.sample_ode_from_base(torch.zeros(0, 16, device=DEV), method="euler", options=opts)
+    assert out.shape == (0, 16)
+    net = sm._net()
+    tab = sm._ode_table(torch.tensor([1.0, 1e-3]), "euler", opts, 0)
+    x = torch.randn(10, 16, device=DEV)
+    x[3, 5] = float("nan")
+    _, _, status = net.integrate(x, tab, 0)
+    assert int(status.item()) & 1
+    _, _, status = net.integrate(torch.randn(10, 16, device=DEV), tab, 0)
+    assert int(status.item()) == 0
+
+
+def test_unsupported_shapes_raise_on_gpu():
+    from flowfusion_amd import flow as Fm
+    f = Fm.ODEFlow(64, [512] * 5).to(DEV).eval()                  # BASELINE config 4: kernel not built yet
+    with pytest.raises(NotImplementedError):
+        f.sample(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
+
+
+# ---- full-size properties (BASELINE.json config 2 / 3 shapes) -----------------------------------------------
+FULL_B = 1 << 20
+
+
+def test_full_size_sampling_properties():
+    sm, so32, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 17)
+    eps = float(sm.sde.epsilon)
+    opts = {"step_size": (1.0 - eps) / 100}
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    z = torch.randn(FULL_B, 16, device=DEV, generator=g)
+    x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    assert torch.isfinite(x).all()
+    # determinism: a second launch is bit-identical
+    x2, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    assert torch.equal(x, x2)
+    # batch-shape invariance: any slice solved on its own gives the same bits (samples are independent)
+    for sl in (slice(0, 200), slice(FULL_B // 2 + 5, FULL_B // 2 + 77), slice(FULL_B - 130, FULL_B)):
+        xs, _ = sm.sample_ode_from_base(z[sl].contiguous(), method="rk4", options=opts)
+        assert torch.equal(xs, x[sl])
+    # oracle on a strided subsample of the big run
+    idx = torch.arange(0, FULL_B, FULL_B // 64)
+    ref = so32.sample_ode_from_base(z[idx].cpu(), None, "rk4", opts)
+    assert _state_err(x[idx], ref) < STATE_TOL
+    # reversibility: integrating the result back from epsilon to 1 recovers the base sample
+    sm.hutch = True
+    zT, _ = sm.solve_odes_forward(x, method="rk4", options=opts)
+    err = ((zT - z).abs().max() / z.abs().max()).item()
+    assert err < 5e-3, err
+
+
+def test_full_size_log_prob_properties():
+    sm, so32, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 18)
+    sm.hutch = True
+    eps = float(sm.sde.epsilon)
+    opts = {"step_size": (1.0 - eps) / 100}
+    g = torch.Generator(device=DEV).manual_seed(4321)
+    x0 = torch.randn(FULL_B, 16, device=DEV, generator=g) * 0.9
+    e = torch.sign(torch.randn(FULL_B, 16, device=DEV, generator=g))
+    net = sm._net()
+    tab = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, 1)
+    xT, dlp, status = net.integrate(x0, tab, 1, probe=e)
+    assert int(status.item()) == 0 and torch.isfinite(dlp).all()
+    # e^T J e is even in e: flipping the probe's sign changes nothing, bit for bit
+    xT2, dlp2, _ = net.integrate(x0, tab, 1, probe=-e)
+    assert torch.equal(dlp, dlp2) and torch.equal(xT, xT2)
+    # the state does not depend on the divergence bookkeeping: same xT as the plain solve, bit for bit
+    tab0 = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, 0)
+    xT0, _, _ = net.integrate(x0, tab0, 0)
+    assert torch.equal(xT0, xT)
+    # oracle on a subsample
+    idx = torch.arange(0, FULL_B, FULL_B // 32)
+    lp = dlp[idx].view(-1, 1) + sm.sde.prior(xT[idx].shape).log_prob(xT[idx]).sum(1, keepdim=True)
+    ref = so32.log_prob(x0[idx].cpu(), None, "rk4", opts, "hutch", e[idx].cpu())
+    assert _logp_err(lp, ref) < LOGP_TOL

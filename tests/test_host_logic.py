@@ -1,0 +1,227 @@
+"""CPU tier: host-side logic of the product (no GPU compute).
+
+* the C-ABI library loads here and exports every symbol include/flowfusion_amd.h declares;
+* kernel plan selection and argument checking;
+* the weight packer + evaluation tables, checked end-to-end through a CPU emulation of the kernel's
+  semantics against the oracle (tests/_emulator.py);
+* state_dict compatibility with reference checkpoints (the golden fixtures hold reference
+  state_dicts) and the plain-torch pointwise members against the golden vectors;
+* error behaviour: unsupported requests raise, nothing falls back to the CPU.
+"""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from flowfusion_amd import _native, solvers
+from flowfusion_amd import diffusion as D
+from flowfusion_amd import flow as F
+from flowfusion_amd.fused import MODE_EXACT, MODE_HUTCH, MODE_STATE
+from oracle import flowfusion_oracle as O
+from tests import _emulator as E
+from tests._util import (flow_model, flow_oracle, golden_names, load_golden, max_rel, score_model, score_oracle)
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol(built_library):
+    header = (ROOT / "include" / "flowfusion_amd.h").read_text()
+    declared = set(re.findall(r"\b(ff_[a-z_0-9]+)\s*\(", header))
+    assert {"ff_mlp_plan", "ff_mlp_wpack", "ff_mlp_ode_launch", "ff_version"} <= declared
+    for sym in sorted(declared):
+        assert hasattr(built_library, sym), f"libflowfusion_amd.so does not export {sym}"
+    assert b"gfx950" in built_library.ff_version()
+    assert built_library.ff_kernel_count() >= 1
+    assert built_library.ff_kernel_name(0) is not None
+
+
+def test_plan_selection_and_errors(built_library):
+    p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)
+    assert (p.width, p.dregs, p.cregs) == (256, 8, 0)
+    p = _native.make_plan(2, 0, [128] * 3, MODE_HUTCH)
+    assert (p.width, p.dregs) == (128, 4)
+    p = _native.make_plan(32, 8, [200, 100], MODE_STATE)       # ragged widths pad to the max
+    assert (p.width, p.dregs, p.cregs) == (256, 16, 8)
+    with pytest.raises(NotImplementedError):
+        _native.make_plan(64, 0, [512] * 5, MODE_STATE)          # config-4 shape: not compiled yet
+    with pytest.raises(NotImplementedError):
+        _native.make_plan(32, 0, [64], MODE_EXACT)               # 33 columns do not fit one wavefront
+    # launch argument checking happens before any HIP call
+    bad = _native.OdeArgs()
+    rc = built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(bad), None)
+    assert rc == _native.FF_ERR_BADARG
+
+
+def test_no_cpu_fallback(built_library):
+    sm = D.ScoreModel(D.MLP(4, 0, 8, [64, 64]), D.VPSDE(), no_sigma=True).eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        sm.sample_ode_from_base(torch.randn(8, 4), method="rk4", options={"step_size": 0.1})
+    with pytest.raises(NotImplementedError, match="adaptive"):
+        sm.sample_ode_from_base(torch.randn(8, 4))                # reference default method=dopri5
+    with pytest.raises(NotImplementedError):
+        D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Tanh()), D.VPSDE()).eval() \
+            .sample_ode_from_base(torch.randn(8, 4), method="euler")
+    f = F.ODEFlow(3, [64, 64])
+    with pytest.raises(NotImplementedError):
+        f.sample(torch.randn(4, 3))                              # adaptive default, as in the reference
+    with pytest.raises(RuntimeError, match="GPU"):
+        f.sample(torch.randn(4, 3), method="rk4", options={"step_size": 0.1})
+
+
+# ---- solvers -------------------------------------------------------------------------------------
+def test_plan_ode_rows():
+    eps = 1e-3
+    plan = solvers.plan_ode(torch.tensor([1.0, eps]), "rk4", {"step_size": (1 - eps) / 10})
+    g = O.grid_from_step_size(-torch.tensor([1.0, eps]), (1 - eps) / 10)
+    assert plan.sign == -1.0 and plan.n_steps == g.numel() - 1
+    assert plan.t_eval.numel() == 4 * plan.n_steps
+    torch.testing.assert_close(plan.t_eval[0::4], -g[:-1], rtol=0, atol=0)     # first stage at t0
+    torch.testing.assert_close(plan.t_eval[3::4], -g[1:], rtol=0, atol=0)      # last stage exactly at t1
+    assert plan.flags.view(-1, 4)[:, 3].eq(solvers.FLAG_STEP_END).all() and plan.flags.view(-1, 4)[:, :3].eq(0).all()
+    one = solvers.plan_ode(torch.tensor([0.0, 1.0]), "euler", None)             # no step_size: one step
+    assert one.n_steps == 1 and float(one.cout[0, 0]) == 1.0
+    with pytest.raises(NotImplementedError):
+        solvers.plan_ode(torch.tensor([0.0, 1.0]), "dopri5", None)
+    with pytest.raises(ValueError):
+        solvers.plan_ode(torch.tensor([0.0, 1.0]), "nope", None)
+
+
+def test_euler_maruyama_times():
+    ts, dt = solvers.plan_euler_maruyama(1.0, torch.tensor(1e-3), 100)
+    assert ts.numel() == 100 and ts[0] == 1.0
+    assert abs(float(dt) + (1 - 1e-3) / 100) < 1e-9
+
+
+# ---- state_dict compatibility + pointwise members ---------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("score_"))
+def test_reference_state_dict_loads_and_pointwise_matches(name):
+    meta, a = load_golden(name)
+    sm = score_model(meta, a)                                     # strict load of the reference keys
+    cond = a.get("cond")
+    sm.conditional = cond
+    for i in range(3):
+        t = a[f"t{i}"]
+        with torch.no_grad():
+            got = sm.ode_drift(t, a["x"], conditional=cond)
+        assert max_rel(got, a[f"xdot_{i}"], floor=a[f"xdot_{i}"].abs().max().item()) < 1e-5
+        sm.prob, sm.hutch, sm.e = True, True, a["e"]
+        _, div = sm.forward(t.clone(), (a["x"].clone(), torch.zeros(a["x"].shape[0], 1)))
+        assert max_rel(div.detach(), a[f"div_hutch_{i}"], floor=a[f"div_hutch_{i}"].abs().max().item()) < 3e-5
+        sm.hutch = False
+        _, div = sm.forward(t.clone(), (a["x"].clone(), torch.zeros(a["x"].shape[0], 1)))
+        assert max_rel(div.detach(), a[f"div_exact_{i}"], floor=a[f"div_exact_{i}"].abs().max().item()) < 3e-5
+        sm.prob = False
+
+
+@pytest.mark.parametrize("name", ["flow_3d", "flow_16d_ragged", "cflow_4d_c2", "cflow_8d_c5"])
+def test_flow_state_dict_and_dynamics(name):
+    meta, a = load_golden(name)
+    f = flow_model(meta, a)
+    data_keys = {"x", "cond", "t0", "t1", "t2"} | {k for k in a if k.startswith(("v_", "div_"))}
+    assert set(f.state_dict().keys()) == set(a) - data_keys         # exactly the reference's keys
+    cond = a.get("cond")
+    for j in range(3):
+        t = a[f"t{j}"]
+        with torch.no_grad():
+            v = f.dynamics(t, (a["x"], cond))[0] if cond is not None else f.dynamics(t, (a["x"],))
+        torch.testing.assert_close(v, a[f"v_{j}"], rtol=1e-5, atol=1e-5)
+        states = (a["x"].clone(), cond, torch.zeros(9, 1)) if cond is not None else (a["x"].clone(), torch.zeros(9, 1))
+        div = f.dynamics_with_jacobian(t.clone(), states)[-1]
+        torch.testing.assert_close(div.detach(), a[f"div_{j}"], rtol=3e-5, atol=3e-5)
+
+
+def test_sde_members_match_golden():
+    _, a = load_golden("sde_schedules")
+    t, x = a["t"], a["x"]
+    for key, sde in {"vp": D.VPSDE(), "ve": D.VESDE(), "subvp": D.SUBVPSDE(),
+                     "vp_b": D.VPSDE(0.2, 12.0, 1.0, 1e-2), "ve_b": D.VESDE(0.05, 25.0, 1.0, 1e-4)}.items():
+        torch.testing.assert_close(sde.sigma(t), a[f"{key}_sigma"], rtol=0, atol=0)
+        torch.testing.assert_close(sde.diffusion(t, x), a[f"{key}_diffusion"], rtol=0, atol=0)
+        torch.testing.assert_close(sde.drift(t, x), a[f"{key}_drift"], rtol=0, atol=0)
+        m, s = sde.marginal_prob_scalars(t)
+        torch.testing.assert_close(m, a[f"{key}_mean_scalar"], rtol=0, atol=0)
+        torch.testing.assert_close(s, a[f"{key}_std_scalar"], rtol=0, atol=0)
+        torch.testing.assert_close(sde.prior(x.shape).log_prob(x), a[f"{key}_prior_logprob"], rtol=1e-6, atol=1e-6)
+
+
+# ---- packer + tables, end to end through the emulator -------------------------------------------------
+def _emulate_score(sm, x, table, mode, cond=None, probe=None, noise=None):
+    net = sm._net()
+    plan = _native.plan_words(net.plan(mode))
+    wpack = net.wpack("cpu", mode)
+    return E.emulate(plan, wpack, table, x, cond=cond, probe=probe, noise=noise, mode=mode)
+
+
+@pytest.mark.parametrize("name", golden_names("hybrid_score_"))
+def test_emulated_kernel_matches_hybrid_golden(name, built_library):
+    """packed weights + evaluation table, run through the kernel's semantics on the CPU, reproduce
+    the reference-RHS x restated-stepper vectors (sampling, Hutchinson and exact log-density)."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a)
+    cond = a.get("cond")
+    eps = float(sm.sde.epsilon)
+    for run in meta["runs"]:
+        m, opts = run["method"], {"step_size": run["step_size"]}
+        z = a["base"] * sm.sde.sigma_max if hasattr(sm.sde, "sigma_max") else a["base"]
+        table = sm._ode_table(torch.tensor([1.0, eps]), m, opts, MODE_STATE)
+        x0, _ = _emulate_score(sm, z, table, MODE_STATE, cond)
+        exp = a[f"sample_{m}"]
+        assert max_rel(x0, exp, floor=exp.abs().max().item()) < 3e-5, (name, m)
+        xd = a[f"x_data_{m}"]
+        tab_h = sm._ode_table(torch.tensor([eps, 1.0]), m, opts, MODE_HUTCH)
+        xT, dlp = _emulate_score(sm, xd, tab_h, MODE_HUTCH, cond, probe=a[f"e_{m}"])
+        lp = dlp[:, None] + sm.sde.prior(xT.shape).log_prob(xT.float()).double().sum(1, keepdim=True)
+        assert max_rel(lp, a[f"lp_hutch_{m}"], floor=1.0) < 1e-4, (name, m)
+        assert max_rel(xT, a[f"xT_{m}"], floor=a[f"xT_{m}"].abs().max().item()) < 3e-5
+        if meta["D"] + 1 <= 32:
+            tab_e = sm._ode_table(torch.tensor([eps, 1.0]), m, opts, MODE_EXACT)
+            xT, dlp = _emulate_score(sm, xd, tab_e, MODE_EXACT, cond)
+            lp = dlp[:, None] + sm.sde.prior(xT.shape).log_prob(xT.float()).double().sum(1, keepdim=True)
+            assert max_rel(lp, a[f"lp_exact_{m}"], floor=1.0) < 1e-4, (name, m)
+
+
+@pytest.mark.parametrize("name", golden_names("hybrid_flow") + golden_names("hybrid_cflow"))
+def test_emulated_kernel_matches_hybrid_flow_golden(name, built_library):
+    meta, a = load_golden(name)
+    f = flow_model(meta, a)
+    net = f._net()
+    cond = a.get("cond")
+    cn = None if cond is None else f._norm_cond(cond)
+    for run in meta["runs"]:
+        m, opts = run["method"], {"step_size": run["step_size"]}
+        table = f._table(torch.tensor([1.0, 0.0]), m, opts, MODE_STATE)
+        plan = _native.plan_words(net.plan(MODE_STATE))
+        x0, _ = E.emulate(plan, net.wpack("cpu", MODE_STATE), table, a["xT"], cond=cn, mode=MODE_STATE,
+                          out_scale=f.target_scale, out_shift=f.target_shift)
+        torch.testing.assert_close(x0.float(), a[f"sample_{m}"], rtol=3e-5, atol=3e-5)
+        table = f._table(torch.tensor([0.0, 1.0]), m, opts, MODE_EXACT)
+        plan = _native.plan_words(net.plan(MODE_EXACT))
+        xn = (a[f"x_data_{m}"] - f.target_shift) / f.target_scale
+        xT, logj = E.emulate(plan, net.wpack("cpu", MODE_EXACT), table, xn, cond=cn, mode=MODE_EXACT)
+        lp = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(f.twopi.double()), dim=1) + logj - torch.log(f.target_scale.double()).sum()
+        torch.testing.assert_close(lp.float(), a[f"logprob_{m}"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("sde_") if n != "sde_schedules"])
+def test_emulated_euler_maruyama_matches_reference(name, built_library):
+    """Table built for sample_sde + the reference's captured RNG draws reproduce the reference's
+    own sample_sde output (diffusion.py:510-563)."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a)
+    steps = meta["steps"]
+    ts, dt = solvers.plan_euler_maruyama(torch.as_tensor(sm.sde.T, dtype=torch.float32), sm.sde.epsilon, steps)
+    n = ts.numel()
+    assert n == steps
+    aa, bb, c1, g = sm._schedule(ts, "sde")
+    cout = torch.zeros(n, 8)
+    cout[:, 0] = dt
+    flags = torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32)
+    flags[-1] = solvers.FLAG_STEP_END
+    plan = solvers.EvalPlan(ts, 1.0, torch.zeros(n, dtype=torch.int32), flags, torch.zeros(n, 8), cout, n)
+    table = solvers.build_table(plan, aa, bb, c1, sm._net().width(MODE_STATE), gn=g * (-dt) ** 0.5,
+                                noise_idx=torch.arange(n))
+    x, _ = _emulate_score(sm, a["x_prior"], table, MODE_STATE, a.get("cond"), noise=a["noise"])
+    assert max_rel(x, a["out"], floor=a["out"].abs().max().item()) < 3e-5

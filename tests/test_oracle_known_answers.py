@@ -1,0 +1,115 @@
+"""Known-answer tests that do not depend on any stepper implementation other than the one under
+test: convergence order of the restated fixed-grid schemes, time reversal, the grid rule, and
+closed-form Gaussian densities pushed through the probability-flow ODE."""
+import math
+
+import pytest
+import torch
+
+from oracle import flowfusion_oracle as O
+
+
+def _solve_linear(method, n, t0=0.0, t1=1.0, dtype=torch.float64):
+    # dy/dt = -2 t y + cos(3t) has a smooth non-polynomial solution; compare two resolutions with a fine one
+    f = lambda t, y: (-2.0 * t * y[0] + torch.cos(3.0 * t),)
+    y0 = (torch.tensor([1.0, -0.5], dtype=dtype),)
+    t = torch.tensor([t0, t1], dtype=dtype)
+    (y,) = O.odeint_fixed(f, y0, t, method, {"step_size": abs(t1 - t0) / n})
+    return y
+
+
+@pytest.mark.parametrize("method,order", [("euler", 1), ("midpoint", 2), ("heun3", 3), ("rk4", 4),
+                                          ("rk4_classic", 4), ("dopri5_fixed", 5)])
+def test_convergence_order(method, order):
+    ref = _solve_linear("dopri5_fixed", 4000)
+    e1 = (_solve_linear(method, 20) - ref).abs().max().item()
+    e2 = (_solve_linear(method, 40) - ref).abs().max().item()
+    observed = math.log2(e1 / e2)
+    assert abs(observed - order) < 0.35, (method, observed)
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+def test_reversed_span_equals_negated_problem(method):
+    """Solving t: 1 -> 0 must equal solving s = -t: -1 -> 0 of the negated field (how torchdiffeq does it)."""
+    f = lambda t, y: (torch.sin(t) * y[0] + t,)
+    y0 = (torch.tensor([0.3, 1.2], dtype=torch.float64),)
+    (a,) = O.odeint_fixed(f, y0, torch.tensor([1.0, 0.0], dtype=torch.float64), method, {"step_size": 0.05})
+    g = lambda s, y: (-(torch.sin(-s) * y[0] + (-s)),)
+    (b,) = O.odeint_fixed(g, y0, torch.tensor([-1.0, 0.0], dtype=torch.float64), method, {"step_size": 0.05})
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_grid_rule():
+    t = torch.tensor([0.0, 1.0])
+    g = O.grid_from_step_size(t, 0.25)
+    torch.testing.assert_close(g, torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0]))
+    g = O.grid_from_step_size(t, 0.3)       # last interval is cut short at t1
+    torch.testing.assert_close(g, torch.tensor([0.0, 0.3, 0.6, 0.9, 1.0]))
+    # no step_size: the grid is t itself -> a single step
+    f = lambda tt, y: (y[0],)
+    (y,) = O.odeint_fixed(f, (torch.ones(1, dtype=torch.float64),), torch.tensor([0.0, 1.0], dtype=torch.float64), "euler", None)
+    assert y.item() == 2.0
+
+
+class _GaussianScore(O.ScoreOracle):
+    """Analytic score of data ~ N(mu, s^2 I) diffused by the SDE: the marginal at time t is
+    N(m_t mu, (m_t s)^2 + sigma_t^2)."""
+
+    def __init__(self, sde, mu, s, dtype=torch.float64):
+        self.sde, self.mu, self.s, self.dtype, self.no_sigma = sde, mu, s, dtype, True
+
+    def moments(self, t):
+        if self.sde.kind == "ve":
+            m, sig = torch.ones_like(t), self.sde.sigma(t)
+        else:
+            m, sig = self.sde.marginal_prob_scalars(t)
+        return m, (m * self.s) ** 2 + sig ** 2
+
+    def score(self, t, x, conditional=None):
+        t = t * torch.ones(x.shape[0], dtype=x.dtype) if t.dim() == 0 else t
+        m, var = self.moments(t)
+        return -(x - m[:, None] * self.mu) / var[:, None]
+
+
+def _gauss_logpdf(x, mean, var):
+    d = x.shape[1]
+    return -0.5 * ((x - mean) ** 2).sum(1) / var - 0.5 * d * torch.log(2 * math.pi * var)
+
+
+@pytest.mark.parametrize("sde_name", ["vp", "ve", "subvp"])
+def test_gaussian_density_through_pf_ode(sde_name):
+    dt = torch.float64
+    sde = {"vp": O.VP(dtype=dt), "ve": O.VE(epsilon=1e-3, dtype=dt), "subvp": O.SubVP(dtype=dt)}[sde_name]
+    D = 3
+    mu = torch.tensor([0.5, -1.0, 2.0], dtype=dt)
+    s = 0.6
+    so = _GaussianScore(sde, mu, s)
+    torch.manual_seed(0)
+    x0 = mu + s * torch.randn(64, D, dtype=dt)
+    eps = sde.epsilon
+    errs = []
+    for n in (40, 80):
+        opts = {"step_size": float((1.0 - eps) / n)}
+        xT, dlp = so.solve_odes_forward(x0, None, "rk4", opts, divergence="exact")
+        m1, v1 = so.moments(torch.tensor([1.0], dtype=dt))
+        me, ve = so.moments(eps.reshape(1))
+        lhs = _gauss_logpdf(xT, m1 * mu, v1) + dlp.squeeze(1)      # log p_1(x(1)) + int div
+        rhs = _gauss_logpdf(x0, me * mu, ve)                        # log p_eps(x(eps))
+        errs.append((lhs - rhs).abs().max().item())
+    assert errs[1] < 2e-4, errs
+    assert errs[1] < errs[0] / 6.0, errs        # ~4th order (16x per halving; loose bound)
+
+
+def test_gaussian_sampling_transport():
+    """PF-ODE transport of a Gaussian is affine and known in closed form: x(eps) = m_e mu + sqrt(v_e/v_1) (x(1) - m_1 mu)."""
+    dt = torch.float64
+    sde = O.VP(dtype=dt)
+    mu = torch.tensor([1.0, -2.0], dtype=dt)
+    so = _GaussianScore(sde, mu, 0.8)
+    torch.manual_seed(1)
+    z = torch.randn(32, 2, dtype=dt)
+    x = so.sample_ode_from_base(z, None, "rk4", {"step_size": float((1.0 - sde.epsilon) / 200)})
+    m1, v1 = so.moments(torch.tensor([1.0], dtype=dt))
+    me, ve = so.moments(sde.epsilon.reshape(1))
+    expect = me * mu + torch.sqrt(ve / v1) * (z - m1 * mu)
+    torch.testing.assert_close(x, expect, rtol=1e-6, atol=1e-6)
