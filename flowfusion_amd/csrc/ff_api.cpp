@@ -95,65 +95,49 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
     for (int i = 0; i <= NH; ++i)
         if (!W[i] || (i > 0 && !b[i])) return FF_ERR_BADARG;
     const ff::Layout L = ff::make_layout(H, plan->dregs, plan->cregs, NH);
-    const int NB = L.NB;
     memset(out, 0, L.total_floats * sizeof(float));
 
+    // Fill the chunks of one layer in consumption order (ff_layout.h).  `kcol(r, h)` maps operand
+    // register r on lane-half h to a column of `Wl` (or -1 for padding), rows beyond `rows` are zero.
+    auto fill = [&](const ff::LayerGeom& G, float* o, const float* Wl, int rows, int ld, auto kcol) {
+        for (int c = 0; c < G.NC; ++c) {
+            const int g = ff::chunk_group(G, c), ob = ff::chunk_block(G, c);
+            for (int lane = 0; lane < 64; ++lane)
+                for (int q = 0; q < 4; ++q) {
+                    const int row = ob * 32 + (lane & 31);
+                    const int col = kcol(4 * g + q, lane >> 5);
+                    o[((size_t)c * 64 + lane) * 4 + q] = (row < rows && col >= 0) ? Wl[(size_t)row * ld + col] : 0.f;
+                }
+        }
+    };
     // first layer: operand registers = [state | conditional]
-    {
-        float* o = out + L.off_l1();
-        const int KR = plan->dregs + plan->cregs;
-        const int w0 = hidden_widths[0];
-        for (int g = 0; g < KR / 4; ++g)
-            for (int ob = 0; ob < NB; ++ob)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
-                        int colidx = -1;
-                        if (r < plan->dregs) {
-                            const int d = ff::feat_of_reg(r, h);
-                            if (d < D) colidx = x_col0 + d;
-                        } else {
-                            const int d = ff::feat_of_reg(r - plan->dregs, h);
-                            if (d < C) colidx = c_col0 + d;
-                        }
-                        float v = 0.f;
-                        if (row < w0 && colidx >= 0) v = W[0][(size_t)row * in_features0 + colidx];
-                        o[((size_t)(g * NB + ob) * 64 + lane) * 4 + q] = v;
-                    }
-    }
+    fill(L.g1, out, W[0], hidden_widths[0], in_features0, [&](int r, int h) {
+        if (r < plan->dregs) {
+            const int d = ff::feat_of_reg(r, h);
+            return d < D ? x_col0 + d : -1;
+        }
+        const int d = ff::feat_of_reg(r - plan->dregs, h);
+        return d < C ? c_col0 + d : -1;
+    });
     // hidden -> hidden
     for (int l = 1; l < NH; ++l) {
-        float* o = out + L.off_hid(l - 1);
         const int win = hidden_widths[l - 1], wout = hidden_widths[l];
-        for (int g = 0; g < NB * 4; ++g)
-            for (int ob = 0; ob < NB; ++ob)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
-                        const int k = ff::feat_of_reg(r, h);
-                        float v = 0.f;
-                        if (row < wout && k < win) v = W[l][(size_t)row * win + k];
-                        o[((size_t)(g * NB + ob) * 64 + lane) * 4 + q] = v;
-                    }
-        float* ob_ = o + L.hid_w_floats;
-        for (int row = 0; row < wout; ++row) ob_[row] = b[l][row];
+        fill(L.gh, out + (size_t)L.chunk_off_hid(l - 1) * ff::kChunkFloats, W[l], wout, win, [&](int r, int h) {
+            const int k = ff::feat_of_reg(r, h);
+            return k < win ? k : -1;
+        });
+        float* bo = out + L.bias_off_hid(l - 1);
+        for (int row = 0; row < wout; ++row) bo[row] = b[l][row];
     }
     // output layer
     {
-        float* o = out + L.off_out();
         const int win = hidden_widths[NH - 1];
-        for (int g = 0; g < NB * 4; ++g)
-            for (int ob = 0; ob < L.nob_out; ++ob)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = 4 * g + q, h = lane >> 5, row = ob * 32 + (lane & 31);
-                        const int k = ff::feat_of_reg(r, h);
-                        float v = 0.f;
-                        if (row < D && k < win) v = W[NH][(size_t)row * win + k];
-                        o[((size_t)(g * L.nob_out + ob) * 64 + lane) * 4 + q] = v;
-                    }
-        float* ob_ = o + L.out_w_floats;
-        for (int row = 0; row < D; ++row) ob_[row] = b[NH][row];
+        fill(L.go, out + (size_t)L.chunk_off_out() * ff::kChunkFloats, W[NH], D, win, [&](int r, int h) {
+            const int k = ff::feat_of_reg(r, h);
+            return k < win ? k : -1;
+        });
+        float* bo = out + L.bias_off_out();
+        for (int row = 0; row < D; ++row) bo[row] = b[NH][row];
     }
     return FF_OK;
 }

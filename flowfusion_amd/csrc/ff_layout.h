@@ -14,10 +14,18 @@
 //     long as the A operand (the weights) is packed in the matching order.  That
 //     packing is what this header defines.
 //
-// Packed A stream of one layer with KR operand registers (k-steps) and NOB output blocks
-// of 32 rows: for g in [0, KR/4): for ob in [0, NOB): 64 lanes x 4 floats, lane l, float q:
+// A operands are stored as CHUNKS of 1 KiB: 64 lanes x 4 floats; lane l, float q of the chunk
+// for (group g, output block ob) of a layer is
 //       W[ ob*32 + (l & 31) ][ kcol(4*g + q, l >> 5) ]
-// i.e. 1 KiB per (g, ob), read by one 16-byte load per lane that feeds 4 MFMAs.
+// so one 16-byte load per lane feeds 4 MFMAs.  The chunks of one evaluation form a single
+// linear stream in the exact order the kernel consumes them (layer 1, hidden layers, output
+// layer), which lets the kernel prefetch with one uniform sliding window, across layer and
+// evaluation boundaries.  Within a layer of G groups and NOB blocks the order is
+//   phase A (groups 0 .. G-5): group-major  -- all NOB accumulators advance together;
+//   phase B (last min(G,4) groups): block-major -- accumulator ob completes after its last
+//           chunk, so its activation overlaps the MFMAs of block ob+1.
+// Each layer's chunk count is padded to a multiple of kChunkPad (zero chunks, loaded but
+// unused) so the prefetch ring position is a compile-time constant everywhere.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -30,14 +38,55 @@
 
 namespace ff {
 
+constexpr int kChunkFloats = 256;   // 1 KiB
+constexpr int kChunkPad = 16;       // layer chunk counts are padded to a multiple of this
+
 // feature index held by activation/state register r on lane-half h
-FF_HD int feat_of_reg(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h; }
+FF_HD constexpr int feat_of_reg(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h; }
 
 // number of lane registers needed for F features (multiple of 4 registers = 8 features)
-FF_HD int regs_for(int F) { return 4 * ((F + 7) / 8); }
+FF_HD constexpr int regs_for(int F) { return 4 * ((F + 7) / 8); }
 
 // output blocks (32 rows) needed to produce `regs` registers
-FF_HD int blocks_for_regs(int regs) { return (regs + 15) / 16; }
+FF_HD constexpr int blocks_for_regs(int regs) { return (regs + 15) / 16; }
+
+// Chunk order of one layer with KR operand registers and NOB output blocks.
+struct LayerGeom {
+    int G;      // groups of 4 k-steps
+    int NOB;    // output blocks
+    int GB;     // groups in phase B (block-major tail)
+    int GA;     // groups in phase A (group-major)
+    int NC;     // real chunks = G * NOB
+    int CPAD;   // padded chunk count
+};
+
+FF_HD constexpr LayerGeom layer_geom(int KR, int NOB)
+{
+    LayerGeom g{};
+    g.G = KR / 4;
+    g.NOB = NOB;
+    g.GB = g.G < 4 ? g.G : 4;
+    g.GA = g.G - g.GB;
+    g.NC = g.G * NOB;
+    g.CPAD = (g.NC + kChunkPad - 1) / kChunkPad * kChunkPad;
+    return g;
+}
+
+// chunk index -> group (consumption order)
+FF_HD constexpr int chunk_group(const LayerGeom& L, int c)
+{
+    return c < L.GA * L.NOB ? c / L.NOB : L.GA + (c - L.GA * L.NOB) % L.GB;
+}
+// chunk index -> output block
+FF_HD constexpr int chunk_block(const LayerGeom& L, int c)
+{
+    return c < L.GA * L.NOB ? c % L.NOB : (c - L.GA * L.NOB) / L.GB;
+}
+// true if chunk c is the last one that touches its output block
+FF_HD constexpr bool chunk_completes_block(const LayerGeom& L, int c)
+{
+    return c >= L.GA * L.NOB && (c - L.GA * L.NOB) % L.GB == L.GB - 1;
+}
 
 struct Layout {
     int H;        // hidden width on chip (multiple of 32)
@@ -46,31 +95,36 @@ struct Layout {
     int cregs;    // conditional registers
     int n_hidden; // hidden layers
     int nob_out;  // output blocks of the last layer
+    LayerGeom g1, gh, go;   // first layer, hidden->hidden, output layer
 
+    // chunk stream (in chunks)
+    int chunks_l1, chunks_hid, chunks_out, chunks_total;
     // sizes in floats
-    size_t l1_floats;      // first layer: (dregs+cregs)/4 groups x NB blocks x 256
-    size_t hid_w_floats;   // one hidden->hidden layer weights: NB*4 groups x NB x 256
-    size_t hid_floats;     // + bias H
-    size_t out_w_floats;   // output layer weights: NB*4 groups x nob_out x 256
-    size_t out_floats;     // + bias nob_out*32
+    size_t stream_floats;   // chunks_total * 256
+    size_t bias_floats;     // (n_hidden-1) * H + nob_out*32
     size_t total_floats;
 
-    FF_HD size_t off_l1() const { return 0; }
-    FF_HD size_t off_hid(int l /* 0-based index of hidden->hidden layer */) const { return l1_floats + (size_t)l * hid_floats; }
-    FF_HD size_t off_out() const { return l1_floats + (size_t)(n_hidden - 1) * hid_floats; }
+    FF_HD int chunk_off_hid(int l) const { return chunks_l1 + l * chunks_hid; }
+    FF_HD int chunk_off_out() const { return chunks_l1 + (n_hidden - 1) * chunks_hid; }
+    FF_HD size_t bias_off_hid(int l) const { return stream_floats + (size_t)l * H; }
+    FF_HD size_t bias_off_out() const { return stream_floats + (size_t)(n_hidden - 1) * H; }
 };
 
-FF_HD Layout make_layout(int H, int dregs, int cregs, int n_hidden)
+FF_HD constexpr Layout make_layout(int H, int dregs, int cregs, int n_hidden)
 {
-    Layout L;
+    Layout L{};
     L.H = H; L.NB = H / 32; L.dregs = dregs; L.cregs = cregs; L.n_hidden = n_hidden;
     L.nob_out = blocks_for_regs(dregs);
-    L.l1_floats = (size_t)((dregs + cregs) / 4) * L.NB * 256;
-    L.hid_w_floats = (size_t)(L.NB * 4) * L.NB * 256;
-    L.hid_floats = L.hid_w_floats + H;
-    L.out_w_floats = (size_t)(L.NB * 4) * L.nob_out * 256;
-    L.out_floats = L.out_w_floats + (size_t)L.nob_out * 32;
-    L.total_floats = L.l1_floats + (size_t)(n_hidden - 1) * L.hid_floats + L.out_floats;
+    L.g1 = layer_geom(dregs + cregs, L.NB);
+    L.gh = layer_geom(L.NB * 16, L.NB);
+    L.go = layer_geom(L.NB * 16, L.nob_out);
+    L.chunks_l1 = L.g1.CPAD;
+    L.chunks_hid = L.gh.CPAD;
+    L.chunks_out = L.go.CPAD;
+    L.chunks_total = L.chunks_l1 + (n_hidden - 1) * L.chunks_hid + L.chunks_out;
+    L.stream_floats = (size_t)L.chunks_total * kChunkFloats;
+    L.bias_floats = (size_t)(n_hidden - 1) * H + (size_t)L.nob_out * 32;
+    L.total_floats = L.stream_floats + L.bias_floats;
     return L;
 }
 

@@ -14,11 +14,13 @@
 // weight operands (v = Hutchinson probe, or the D unit vectors for the exact trace); the
 // per-column contribution v . (J v) is integrated per lane and reduced once at the end.
 // Activations never leave registers: the 32x32 f32 accumulator tile of layer l, after
-// bias (folded into the accumulator's initial value) and SiLU, is the B operand of layer
-// l+1.  Weights stream from L2 as the A operand, one 16-byte load per lane per 4 MFMAs.
+// bias and SiLU, is the B operand of layer l+1.  Weights stream from L2 as the A operand
+// (one 16-byte load per lane per 4 MFMAs) through a register ring that runs a fixed number
+// of chunks ahead of the MFMAs, across layer and evaluation boundaries.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "ff_layout.h"
 #include "ff_kernel_args.h"
 
@@ -26,7 +28,21 @@ namespace ff {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRing = 8;    // weight chunks (1 KiB each, 4 VGPRs per lane) kept in flight per wavefront
+static_assert(kChunkPad % kRing == 0, "ring must divide the chunk padding");
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: f(std::integral_constant<int, i>) for i in [0, N)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
 {
@@ -58,75 +74,98 @@ __device__ __forceinline__ f32x4 sload(const Stream& s, int voff, int soff)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, voff, soff, 0));
 }
 
-// acc[ob] += W[ob, :] . breg over KR operand registers.  The A stream is consumed in groups
-// of NOB x 16-byte loads (4 k-steps each); group g+1 is requested before the 4*NOB MFMAs of
-// group g are issued, and the compiler is fenced from hoisting loads any further ahead
-// (it would otherwise fill all 512 registers with prefetched weights and spill the state).
-template <int KR, int NOB>
-__device__ __forceinline__ void gemm_kouter(f32x16 (&acc)[NOB], const Stream& ws, int lane16, int wbyte,
-                                            const float (&breg)[KR])
+// 32 bias rows of one output block in accumulator-register order (4 x 16 bytes per lane half)
+struct Bias16 {
+    f32x4 v[4];
+};
+__device__ __forceinline__ Bias16 load_bias(const Stream& s, int half16, int byte_off)
 {
-    constexpr int G = KR / 4;
-    f32x4 A[2][NOB];
+    Bias16 b;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) A[0][ob] = sload(ws, lane16, wbyte + ob * 1024);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (g + 1 < G) {
-#pragma unroll
-            for (int ob = 0; ob < NOB; ++ob)
-                A[(g + 1) & 1][ob] = sload(ws, lane16, wbyte + ((g + 1) * NOB + ob) * 1024);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[ob] = mfma32(A[g & 1][ob][q], breg[g * 4 + q], acc[ob]);
-        }
+    for (int j = 0; j < 4; ++j) b.v[j] = sload(s, half16, byte_off + 32 * j);
+    return b;
+}
+
+// One activation unit: SiLU(pre) on value columns; SiLU'(pre of the value column) * pre on
+// tangent columns (pre = accumulator + bias; tangent columns carry zero bias).
+template <bool TANGENTS>
+__device__ __forceinline__ float act_unit(float pre, bool is_tangent, int value_lane_bytes)
+{
+    const float s = sigmoidf_fast(pre);
+    const float h = pre * s;
+    if constexpr (TANGENTS) {
+        const float d = __builtin_fmaf(h, 1.0f - s, s);
+        const float dv =
+            __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d)));
+        return is_tangent ? dv * pre : h;
+    } else {
+        return h;
     }
 }
 
-// acc[ob] <- bias rows of block ob in accumulator order (zero on tangent columns).
-template <int NOB>
-__device__ __forceinline__ void init_acc(f32x16 (&acc)[NOB], const Stream& bs, int half16, int bbyte,
-                                         bool zero)
+// One layer:  acc[ob] = W[ob,:] . B  over the layer's chunk stream, consumed in the order of
+// ff_layout.h.  `ring` holds the next kRing chunks on entry and on exit (of the following
+// layer); chunk c + kRing is requested right after chunk c's four MFMAs have been issued.
+//
+// The VALU work of the activations is spread one register per MFMA so that it runs in the
+// shadow of the matrix pipe:
+//   * while block ob (>= 1) runs its 16 phase-B MFMAs, `unit(ob-1, i, acc)` finishes register i
+//     of block ob-1;
+//   * the LAST block has no MFMAs behind it in this layer: `last(acc)` only parks it, and the
+//     next layer runs `prev_unit(i)` behind its first 16 MFMAs (its phase A does not read the
+//     last k-block, so those registers are not needed before).
+//   sbyte      byte offset of this layer's chunk 0 in the stream (wave-uniform)
+//   WRAP       the stream ends with this layer: prefetch wraps to offset 0 (next evaluation)
+//   pre_block(ob)  called at the first phase-B chunk of block ob (bias prefetch)
+template <int KR, int NOB, bool WRAP, bool PREV, class PrevFn, class PreFn, class UnitFn, class LastFn>
+__device__ __forceinline__ void run_layer(f32x4 (&ring)[kRing], const Stream& ws, int lane16, int sbyte,
+                                          const float (&B)[KR], PrevFn&& prev_unit, PreFn&& pre_block,
+                                          UnitFn&& unit, LastFn&& last)
 {
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 b = sload(bs, half16, bbyte + (ob * 32 + 8 * j) * 4);
-            if (zero) b = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[ob][4 * j + 0] = b[0];
-            acc[ob][4 * j + 1] = b[1];
-            acc[ob][4 * j + 2] = b[2];
-            acc[ob][4 * j + 3] = b[3];
+    constexpr LayerGeom L = layer_geom(KR, NOB);
+    static_assert(!PREV || L.GA * L.NOB * 4 >= 16, "deferred activation needs 16 phase-A MFMAs");
+    f32x16 acc[NOB];
+    static_for<L.CPAD>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int slot = c % kRing;
+        if constexpr (c < L.NC) {
+            constexpr int g = chunk_group(L, c);
+            constexpr int ob = chunk_block(L, c);
+            constexpr bool phase_b = c >= L.GA * L.NOB;
+            constexpr int cb = phase_b ? (c - L.GA * L.NOB) % L.GB : 0;     // chunk within the block's tail
+            if constexpr (phase_b && cb == 0) pre_block(std::integral_constant<int, ob>{});
+            const f32x4 a = ring[slot];
+            static_for<4>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                if constexpr (g == 0 && q == 0)
+                    acc[ob] = mfma32(a[q], B[4 * g + q], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
+                else
+                    acc[ob] = mfma32(a[q], B[4 * g + q], acc[ob]);
+                constexpr int mi = 4 * c + q;                                  // MFMA index in the layer
+                if constexpr (PREV && mi < 16) prev_unit(std::integral_constant<int, mi>{});
+                if constexpr (phase_b && ob >= 1) {
+                    // the 16 registers of block ob-1 are spread over the 4*GB MFMAs of block ob
+                    constexpr int nm = 4 * L.GB, m = 4 * cb + q;
+                    constexpr int lo = (16 * m + nm - 1) / nm, hi = (16 * (m + 1) + nm - 1) / nm;
+                    static_for<hi - lo>([&](auto uu) {
+                        constexpr int i = lo + decltype(uu)::value;
+                        unit(std::integral_constant<int, ob - 1>{}, std::integral_constant<int, i>{}, acc[ob - 1]);
+                    });
+                }
+            });
+            if constexpr (c == L.NC - 1) last(acc[NOB - 1]);
         }
-    }
-}
-
-// P <- SiLU(acc) on value columns;  P <- SiLU'(a_value) * acc on tangent columns.
-template <int NB, bool TANGENTS>
-__device__ __forceinline__ void activate(float (&P)[NB * 16], const f32x16 (&acc)[NB], bool is_tangent,
-                                         int value_lane_bytes)
-{
-#pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = acc[ob][r];
-            const float s = sigmoidf_fast(a);
-            const float h = a * s;
-            if constexpr (TANGENTS) {
-                const float d = __builtin_fmaf(h, 1.0f - s, s);
-                const float dv = __builtin_bit_cast(
-                    float, __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d)));
-                P[ob * 16 + r] = is_tangent ? dv * a : h;
-            } else {
-                P[ob * 16 + r] = h;
-            }
-        }
-    }
+        constexpr int nxt = c + kRing;
+        if constexpr (WRAP && nxt >= L.CPAD)
+            ring[slot] = sload(ws, lane16, (nxt - L.CPAD) * 1024);
+        else
+            ring[slot] = sload(ws, lane16, sbyte + nxt * 1024);
+        // Pin the stream order: MFMAs and vector-memory loads may not be scheduled across this
+        // point (VALU / SALU / transcendental / DS work of the activations may), so every load
+        // is issued exactly one ring length ahead of its use.
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x80);
+    });
 }
 
 template <int H, int DREGS, int CREGS, bool TANGENTS>
@@ -218,7 +257,13 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     const Layout L = make_layout(H, DREGS, CREGS, args.n_hidden);
     const Stream ws = make_stream(args.wpack, args.wpack_floats);
     const Stream ts = make_stream(args.etab, (long long)args.n_evals * args.etab_stride);
-    const int out_wbyte = (int)(L.off_out() * 4);
+    const int out_sbyte = L.chunk_off_out() * 1024;
+    const int out_bias_byte = (int)(L.bias_off_out() * 4);
+
+    // prefetch ring: the first kRing chunks of layer 1
+    f32x4 ring[kRing];
+#pragma unroll
+    for (int i = 0; i < kRing; ++i) ring[i] = sload(ws, lane16, i * 1024);
 
     float P[NB * 16];
 
@@ -255,32 +300,64 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
             }
         }
 
+        // `pend` = pre-activations (accumulator + bias) of the previous layer's last block; they
+        // are activated into P[(NB-1)*16 ..] behind the first MFMAs of the next layer.
+        float pend[16];
+        Bias16 bias[2];
+        auto bias_reg = [&](const Bias16& b, int r) {
+            const float v = b.v[r >> 2][r & 3];
+            return TANGENTS ? (is_tangent ? 0.f : v) : v;
+        };
+        auto prev_unit = [&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            P[(NB - 1) * 16 + i] = act_unit<TANGENTS>(pend[i], is_tangent, value_lane_bytes);
+        };
+        auto unit = [&](auto ob, auto ii, const f32x16& acc) {
+            constexpr int o = decltype(ob)::value;
+            constexpr int i = decltype(ii)::value;
+            P[o * 16 + i] = act_unit<TANGENTS>(acc[i] + bias_reg(bias[o & 1], i), is_tangent, value_lane_bytes);
+        };
+        auto park_last = [&](const f32x16& acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pend[r] = acc[r] + bias_reg(bias[(NB - 1) & 1], r);
+        };
         // ---- layer 1: [x | cond] -> H, bias c1_e ---------------------------------------
-        {
-            f32x16 acc[NB];
-            init_acc<NB>(acc, ts, half16, row_byte + 128, is_tangent);
-            gemm_kouter<K1, NB>(acc, ws, lane16, 0, y);
-            activate<NB, TANGENTS>(P, acc, is_tangent, value_lane_bytes);
-        }
+        run_layer<K1, NB, false, false>(
+            ring, ws, lane16, 0, y, [](auto) {},
+            [&](auto ob) {
+                constexpr int o = decltype(ob)::value;
+                bias[o & 1] = load_bias(ts, half16, row_byte + 128 + o * 128);
+            },
+            unit, park_last);
         // ---- hidden -> hidden ------------------------------------------------------------
         for (int l = 0; l < args.n_hidden - 1; ++l) {
-            const int wbyte = (int)(L.off_hid(l) * 4);
-            f32x16 acc[NB];
-            init_acc<NB>(acc, ws, half16, wbyte + (int)(L.hid_w_floats * 4), is_tangent);
-            gemm_kouter<NB * 16, NB>(acc, ws, lane16, wbyte, P);
-            activate<NB, TANGENTS>(P, acc, is_tangent, value_lane_bytes);
+            const int sbyte = L.chunk_off_hid(l) * 1024;
+            const int bbyte = (int)(L.bias_off_hid(l) * 4);
+            run_layer<NB * 16, NB, false, true>(
+                ring, ws, lane16, sbyte, P, prev_unit,
+                [&](auto ob) {
+                    constexpr int o = decltype(ob)::value;
+                    bias[o & 1] = load_bias(ws, half16, bbyte + o * 128);
+                },
+                unit, park_last);
         }
         // ---- output layer ----------------------------------------------------------------
         float net[NOB_OUT * 16];
-        {
-            f32x16 acc[NOB_OUT];
-            init_acc<NOB_OUT>(acc, ws, half16, out_wbyte + (int)(L.out_w_floats * 4), is_tangent);
-            gemm_kouter<NB * 16, NOB_OUT>(acc, ws, lane16, out_wbyte, P);
+        run_layer<NB * 16, NOB_OUT, true, true>(
+            ring, ws, lane16, out_sbyte, P, prev_unit,
+            [&](auto ob) {
+                constexpr int o = decltype(ob)::value;
+                bias[o & 1] = load_bias(ws, half16, out_bias_byte + o * 128);
+            },
+            [&](auto ob, auto ii, const f32x16& acc) {
+                constexpr int o = decltype(ob)::value;
+                constexpr int i = decltype(ii)::value;
+                net[o * 16 + i] = acc[i] + bias_reg(bias[o & 1], i);
+            },
+            [&](const f32x16& acc) {
 #pragma unroll
-            for (int ob = 0; ob < NOB_OUT; ++ob)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) net[ob * 16 + r] = acc[ob][r];
-        }
+                for (int r = 0; r < 16; ++r) net[(NOB_OUT - 1) * 16 + r] = acc[r] + bias_reg(bias[(NOB_OUT - 1) & 1], r);
+            });
 
         // ---- RHS and stage bookkeeping -----------------------------------------------------
         float rhs[DREGS];

@@ -13,50 +13,53 @@ def feat_of_reg(r, h):
     return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h
 
 
+def _geom(KR, NOB):
+    G = KR // 4
+    GB = min(G, 4)
+    GA = G - GB
+    NC = G * NOB
+    return dict(G=G, NOB=NOB, GB=GB, GA=GA, NC=NC, CPAD=(NC + 15) // 16 * 16)
+
+
+def _chunk_gob(L, c):
+    na = L["GA"] * L["NOB"]
+    if c < na:
+        return c // L["NOB"], c % L["NOB"]
+    return L["GA"] + (c - na) % L["GB"], (c - na) // L["GB"]
+
+
 def decode_wpack(plan, wpack):
-    """Invert the packing: dense (zero padded) matrices W1[H, 2*dregs + 2*cregs], hidden [H,H]+bias, out."""
+    """Invert the packing (csrc/ff_layout.h): dense zero-padded matrices W1[H, 2*dregs + 2*cregs],
+    hidden [H,H] + bias[H], output [nob_out*32, H] + bias."""
     D, C, NH, H, dregs, cregs = plan[0], plan[1], plan[2], plan[3], plan[4], plan[5]
     NB = H // 32
     nob_out = (dregs + 15) // 16
     w = wpack.double()
-    pos = 0
+    g1, gh, go = _geom(dregs + cregs, NB), _geom(NB * 16, NB), _geom(NB * 16, nob_out)
+    stream = g1["CPAD"] + (NH - 1) * gh["CPAD"] + go["CPAD"]
 
-    def take(n):
-        nonlocal pos
-        out = w[pos:pos + n]
-        pos += n
-        return out
-
-    def decode(KR, NOB, kdim):
-        blk = take((KR // 4) * NOB * 256).view(KR // 4, NOB, 64, 4)
-        M = torch.zeros(NOB * 32, kdim, dtype=torch.float64)
-        for g in range(KR // 4):
+    def decode(L, chunk0, kdim, kmap):
+        M = torch.zeros(L["NOB"] * 32, kdim, dtype=torch.float64)
+        blk = w[chunk0 * 256:(chunk0 + L["CPAD"]) * 256].view(L["CPAD"], 64, 4)
+        assert blk[L["NC"]:].abs().sum() == 0                    # padding chunks are zero
+        for c in range(L["NC"]):
+            g, ob = _chunk_gob(L, c)
             for q in range(4):
-                r = 4 * g + q
                 for h in (0, 1):
-                    k = kmap(r, h)
-                    if k is None:
-                        continue
-                    lanes = torch.arange(32) + 32 * h
-                    for ob in range(NOB):
-                        M[ob * 32:(ob + 1) * 32, k] = blk[g, ob, lanes, q]
+                    k = kmap(4 * g + q, h)
+                    M[ob * 32:(ob + 1) * 32, k] = blk[c, 32 * h:32 * h + 32, q]
         return M
 
-    # first layer: columns [x dims (2*dregs) | cond dims (2*cregs)]
-    def kmap(r, h):
-        return feat_of_reg(r, h) if r < dregs else 2 * dregs + feat_of_reg(r - dregs, h)
-    W1 = decode(dregs + cregs, NB, 2 * dregs + 2 * cregs)
-
-    def kmap(r, h):   # noqa: F811
-        return feat_of_reg(r, h)
+    W1 = decode(g1, 0, 2 * dregs + 2 * cregs,
+                lambda r, h: feat_of_reg(r, h) if r < dregs else 2 * dregs + feat_of_reg(r - dregs, h))
     hidden = []
-    for _ in range(NH - 1):
-        Wl = decode(NB * 16, NB, H)
-        bl = take(H)
-        hidden.append((Wl, bl))
-    Wo = decode(NB * 16, nob_out, H)
-    bo = take(nob_out * 32)
-    assert pos == w.numel(), (pos, w.numel())
+    bias0 = stream * 256
+    for l in range(NH - 1):
+        Wl = decode(gh, g1["CPAD"] + l * gh["CPAD"], H, feat_of_reg)
+        hidden.append((Wl, w[bias0 + l * H: bias0 + (l + 1) * H]))
+    Wo = decode(go, g1["CPAD"] + (NH - 1) * gh["CPAD"], H, feat_of_reg)
+    bo = w[bias0 + (NH - 1) * H: bias0 + (NH - 1) * H + nob_out * 32]
+    assert bias0 + (NH - 1) * H + nob_out * 32 == w.numel()
     return W1, hidden, Wo, bo
 
 
