@@ -30,6 +30,7 @@ struct KernelArgs {
     int unit_tangents;   // 1: tangents are unit vectors (exact trace); 0: tangent = probe[sample]
     int etab_stride;     // floats per evaluation row = FF_ROW_HDR + H
     int wpack_floats;    // size of wpack (bounds of the buffer resource)
+    unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
 };
 
 } // namespace ff

@@ -86,54 +86,85 @@ __device__ __forceinline__ Bias16 load_bias(const Stream& s, int half16, int byt
     return b;
 }
 
-// One activation unit: SiLU(pre) on value columns; SiLU'(pre of the value column) * pre on
-// tangent columns (pre = accumulator + bias; tangent columns carry zero bias).
-template <bool TANGENTS>
-__device__ __forceinline__ float act_unit(float pre, bool is_tangent, int value_lane_bytes)
+// Activation of 4 registers, cut into stages that are issued one MFMA apart, so that no
+// instruction waits on the one just before it (a lone SiLU chain  add -> mul -> exp -> add -> rcp ->
+// mul  costs ~100 cycles of back-to-back latency; the in-order wavefront would hold the next
+// MFMA behind it).  Value columns: P = SiLU(pre).  Tangent columns: P = SiLU'(pre of the
+// sample's value column) * pre, with SiLU' fetched across lanes by ds_bpermute (stage 3) and
+// consumed one stage later.  pre = accumulator + bias (zero bias on tangent columns).
+struct ActGroup {
+    float pre[4], t[4], r[4], h[4];
+    int dv[4];
+};
+template <bool TANGENTS, int STAGE>
+__device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, bool is_tangent,
+                                          int value_lane_bytes)
 {
-    const float s = sigmoidf_fast(pre);
-    const float h = pre * s;
-    if constexpr (TANGENTS) {
-        const float d = __builtin_fmaf(h, 1.0f - s, s);
-        const float dv =
-            __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d)));
-        return is_tangent ? dv * pre : h;
-    } else {
-        return h;
+    // scalar code on purpose: packed f32 VALU (v_pk_*) issued beside MFMAs costs more than it saves
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (STAGE == 0) {
+            g.t[i] = g.pre[i] * -1.44269504088896340736f;      // exp(-pre) = exp2(-pre * log2 e)
+        } else if constexpr (STAGE == 1) {
+            g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);
+        } else if constexpr (STAGE == 2) {
+            g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
+        } else if constexpr (STAGE == 3) {
+            g.h[i] = g.pre[i] * g.r[i];
+            if constexpr (TANGENTS) {
+                const float d = __builtin_fmaf(g.h[i], 1.0f - g.r[i], g.r[i]);
+                g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d));
+            } else {
+                dst[i] = g.h[i];
+            }
+        } else {
+            if constexpr (TANGENTS) dst[i] = is_tangent ? __builtin_bit_cast(float, g.dv[i]) * g.pre[i] : g.h[i];
+        }
     }
 }
+constexpr int kActStages = 5;
+
+#ifdef FF_DEBUG_STAMPS
+// Diagnostic build: cycle stamps (s_memtime) of wavefront 0, written to a buffer nothing else reads.
+__device__ __forceinline__ void ff_stamp(unsigned long long* buf, int& n, bool on)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    buf[(on && n < 4095) ? n : 4095] = t;      // branch-free: everyone else scribbles on the last slot
+    ++n;
+}
+#endif
 
 // One layer:  acc[ob] = W[ob,:] . B  over the layer's chunk stream, consumed in the order of
 // ff_layout.h.  `ring` holds the next kRing chunks on entry and on exit (of the following
 // layer); chunk c + kRing is requested right after chunk c's four MFMAs have been issued.
 //
-// The VALU work of the activations is spread one register per MFMA so that it runs in the
-// shadow of the matrix pipe:
-//   * while block ob (>= 1) runs its 16 phase-B MFMAs, `unit(ob-1, i, acc)` finishes register i
-//     of block ob-1;
-//   * the LAST block has no MFMAs behind it in this layer: `last(acc)` only parks it, and the
-//     next layer runs `prev_unit(i)` behind its first 16 MFMAs (its phase A does not read the
-//     last k-block, so those registers are not needed before).
-//   sbyte      byte offset of this layer's chunk 0 in the stream (wave-uniform)
-//   WRAP       the stream ends with this layer: prefetch wraps to offset 0 (next evaluation)
+//   sbyte          byte offset of this layer's chunk 0 in the stream (wave-uniform)
+//   WRAP           the stream ends with this layer: prefetch wraps to offset 0 (next evaluation)
 //   pre_block(ob)  called at the first phase-B chunk of block ob (bias prefetch)
-template <int KR, int NOB, bool WRAP, bool PREV, class PrevFn, class PreFn, class UnitFn, class LastFn>
+//   slot(M, acc)   called after the M-th MFMA of the layer has been issued, and kActStages more
+//                  times after the last one: the caller hangs the activation stages of finished
+//                  blocks on these slots so that VALU work runs in the shadow of the matrix pipe
+//   last(acc)      called once the last block's accumulator is complete
+template <int KR, int NOB, bool WRAP, class PreFn, class SlotFn, class LastFn, class DbgFn>
 __device__ __forceinline__ void run_layer(f32x4 (&ring)[kRing], const Stream& ws, int lane16, int sbyte,
-                                          const float (&B)[KR], PrevFn&& prev_unit, PreFn&& pre_block,
-                                          UnitFn&& unit, LastFn&& last)
+                                          const float (&B)[KR], PreFn&& pre_block, SlotFn&& slot_fn,
+                                          LastFn&& last, DbgFn&& dbg)
 {
     constexpr LayerGeom L = layer_geom(KR, NOB);
-    static_assert(!PREV || L.GA * L.NOB * 4 >= 16, "deferred activation needs 16 phase-A MFMAs");
     f32x16 acc[NOB];
+    dbg();
     static_for<L.CPAD>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         constexpr int slot = c % kRing;
+        if constexpr (c == L.GA * L.NOB && c > 0) dbg();
         if constexpr (c < L.NC) {
             constexpr int g = chunk_group(L, c);
             constexpr int ob = chunk_block(L, c);
             constexpr bool phase_b = c >= L.GA * L.NOB;
-            constexpr int cb = phase_b ? (c - L.GA * L.NOB) % L.GB : 0;     // chunk within the block's tail
-            if constexpr (phase_b && cb == 0) pre_block(std::integral_constant<int, ob>{});
+            if constexpr (phase_b && (c - L.GA * L.NOB) % L.GB == 0) pre_block(std::integral_constant<int, ob>{});
             const f32x4 a = ring[slot];
             static_for<4>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
@@ -142,19 +173,16 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[kRing], const Stream& ws
                                                                  0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
                 else
                     acc[ob] = mfma32(a[q], B[4 * g + q], acc[ob]);
-                constexpr int mi = 4 * c + q;                                  // MFMA index in the layer
-                if constexpr (PREV && mi < 16) prev_unit(std::integral_constant<int, mi>{});
-                if constexpr (phase_b && ob >= 1) {
-                    // the 16 registers of block ob-1 are spread over the 4*GB MFMAs of block ob
-                    constexpr int nm = 4 * L.GB, m = 4 * cb + q;
-                    constexpr int lo = (16 * m + nm - 1) / nm, hi = (16 * (m + 1) + nm - 1) / nm;
-                    static_for<hi - lo>([&](auto uu) {
-                        constexpr int i = lo + decltype(uu)::value;
-                        unit(std::integral_constant<int, ob - 1>{}, std::integral_constant<int, i>{}, acc[ob - 1]);
-                    });
-                }
+                slot_fn(std::integral_constant<int, 4 * c + q>{}, acc);
             });
-            if constexpr (c == L.NC - 1) last(acc[NOB - 1]);
+            if constexpr (c == L.NC - 1) {
+                dbg();
+                last(acc[NOB - 1]);
+                static_for<kActStages>([&](auto tt) {
+                    slot_fn(std::integral_constant<int, 4 * L.NC + decltype(tt)::value>{}, acc);
+                });
+                dbg();
+            }
         }
         constexpr int nxt = c + kRing;
         if constexpr (WRAP && nxt >= L.CPAD)
@@ -166,6 +194,24 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[kRing], const Stream& ws
         // is issued exactly one ring length ahead of its use.
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x80);
     });
+}
+
+template <int KR, int NOB>
+struct GeomTag {
+    static constexpr LayerGeom value = layer_geom(KR, NOB);
+};
+
+// Activation schedule of a layer with geometry L: group gi (4 registers) of block blk (< NOB-1)
+// starts its stages at MFMA slot  pb + (blk+1)*4*GB + gi*GB  (pb = first phase-B MFMA), i.e. as soon
+// as block blk+1 has started -- its accumulator is then complete.  Returns the flat group id
+// (blk*4 + gi) whose stage `k` falls on slot M, or -1.
+FF_HD constexpr int act_group_at(const LayerGeom& L, int M, int k)
+{
+    const int s0 = M - 4 * L.GA * L.NOB - k;
+    if (s0 < 4 * L.GB || s0 % L.GB != 0) return -1;
+    const int q = s0 / L.GB;
+    const int blk = q / 4 - 1, gi = q % 4;
+    return blk <= L.NOB - 2 ? blk * 4 + gi : -1;
 }
 
 template <int H, int DREGS, int CREGS, bool TANGENTS>
@@ -266,6 +312,10 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     for (int i = 0; i < kRing; ++i) ring[i] = sload(ws, lane16, i * 1024);
 
     float P[NB * 16];
+#ifdef FF_DEBUG_STAMPS
+    int stamp_n = 0;
+    const bool stamp_on = (blockIdx.x == 0 && threadIdx.x == 0 && args.debug_stamps != nullptr);
+#endif
 
     for (int e = 0; e < args.n_evals; ++e) {
         const int row_byte = e * args.etab_stride * 4;
@@ -300,64 +350,116 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
             }
         }
 
+#ifdef FF_DEBUG_STAMPS
+        auto dbg = [&]() { ff_stamp(args.debug_stamps, stamp_n, stamp_on); };
+        dbg();
+#else
+        auto dbg = []() {};
+#endif
         // `pend` = pre-activations (accumulator + bias) of the previous layer's last block; they
-        // are activated into P[(NB-1)*16 ..] behind the first MFMAs of the next layer.
+        // are activated into P[(NB-1)*16 ..] behind the first MFMAs of the next layer, whose
+        // phase A does not read the last k-block.
         float pend[16];
         Bias16 bias[2];
-        auto bias_reg = [&](const Bias16& b, int r) {
+        ActGroup ag[12];         // in-flight groups: [0,4) parked block of the previous layer, 4 + id % 8 own blocks
+        auto bias1 = [&](const Bias16& b, int r) {
             const float v = b.v[r >> 2][r & 3];
             return TANGENTS ? (is_tangent ? 0.f : v) : v;
         };
-        auto prev_unit = [&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            P[(NB - 1) * 16 + i] = act_unit<TANGENTS>(pend[i], is_tangent, value_lane_bytes);
+        // stages of the previous layer's parked block: group gi starts at slot 4*gi
+        auto prev_slot = [&](auto mm) {
+            constexpr int M = decltype(mm)::value;
+            static_for<kActStages>([&](auto kk) {
+                constexpr int k = kActStages - 1 - decltype(kk)::value;     // oldest group first
+                constexpr int s0 = M - k;
+                if constexpr (s0 >= 0 && s0 < 16 && s0 % 4 == 0) {
+                    constexpr int gi = s0 / 4;
+                    if constexpr (k == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ag[gi].pre[i] = pend[4 * gi + i];
+                    }
+                    act_stage<TANGENTS, k>(ag[gi], &P[(NB - 1) * 16 + 4 * gi], is_tangent, value_lane_bytes);
+                }
+            });
         };
-        auto unit = [&](auto ob, auto ii, const f32x16& acc) {
-            constexpr int o = decltype(ob)::value;
-            constexpr int i = decltype(ii)::value;
-            P[o * 16 + i] = act_unit<TANGENTS>(acc[i] + bias_reg(bias[o & 1], i), is_tangent, value_lane_bytes);
+        // stages of this layer's own blocks 0 .. NB-2 (geometry G), hung on slot M
+        auto own_slot = [&](auto geom, auto mm, const f32x16 (&acc)[NB]) {
+            constexpr LayerGeom G = decltype(geom)::value;
+            constexpr int M = decltype(mm)::value;
+            static_for<kActStages>([&](auto kk) {
+                constexpr int k = kActStages - 1 - decltype(kk)::value;     // oldest group first
+                constexpr int id = act_group_at(G, M, k);
+                if constexpr (id >= 0) {
+                    constexpr int blk = id / 4, gi = id % 4;
+                    if constexpr (k == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            ag[4 + id % 8].pre[i] = acc[blk][4 * gi + i] + bias1(bias[blk & 1], 4 * gi + i);
+                    }
+                    act_stage<TANGENTS, k>(ag[4 + id % 8], &P[blk * 16 + 4 * gi], is_tangent, value_lane_bytes);
+                }
+            });
         };
         auto park_last = [&](const f32x16& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pend[r] = acc[r] + bias_reg(bias[(NB - 1) & 1], r);
+            for (int r = 0; r < 16; ++r) pend[r] = acc[r] + bias1(bias[(NB - 1) & 1], r);
         };
         // ---- layer 1: [x | cond] -> H, bias c1_e ---------------------------------------
-        run_layer<K1, NB, false, false>(
-            ring, ws, lane16, 0, y, [](auto) {},
-            [&](auto ob) {
-                constexpr int o = decltype(ob)::value;
-                bias[o & 1] = load_bias(ts, half16, row_byte + 128 + o * 128);
-            },
-            unit, park_last);
+        {
+            using G1 = GeomTag<K1, NB>;
+            run_layer<K1, NB, false>(
+                ring, ws, lane16, 0, y,
+                [&](auto ob) {
+                    constexpr int o = decltype(ob)::value;
+                    bias[o & 1] = load_bias(ts, half16, row_byte + 128 + o * 128);
+                },
+                [&](auto mm, const f32x16 (&acc)[NB]) { own_slot(G1{}, mm, acc); }, park_last, dbg);
+        }
         // ---- hidden -> hidden ------------------------------------------------------------
         for (int l = 0; l < args.n_hidden - 1; ++l) {
+            using GH = GeomTag<NB * 16, NB>;
             const int sbyte = L.chunk_off_hid(l) * 1024;
             const int bbyte = (int)(L.bias_off_hid(l) * 4);
-            run_layer<NB * 16, NB, false, true>(
-                ring, ws, lane16, sbyte, P, prev_unit,
+            run_layer<NB * 16, NB, false>(
+                ring, ws, lane16, sbyte, P,
                 [&](auto ob) {
                     constexpr int o = decltype(ob)::value;
                     bias[o & 1] = load_bias(ws, half16, bbyte + o * 128);
                 },
-                unit, park_last);
+                [&](auto mm, const f32x16 (&acc)[NB]) {
+                    prev_slot(mm);
+                    own_slot(GH{}, mm, acc);
+                },
+                park_last, dbg);
         }
         // ---- output layer ----------------------------------------------------------------
         float net[NOB_OUT * 16];
-        run_layer<NB * 16, NOB_OUT, true, true>(
-            ring, ws, lane16, out_sbyte, P, prev_unit,
+        run_layer<NB * 16, NOB_OUT, true>(
+            ring, ws, lane16, out_sbyte, P,
             [&](auto ob) {
                 constexpr int o = decltype(ob)::value;
                 bias[o & 1] = load_bias(ws, half16, out_bias_byte + o * 128);
             },
-            [&](auto ob, auto ii, const f32x16& acc) {
-                constexpr int o = decltype(ob)::value;
-                constexpr int i = decltype(ii)::value;
-                net[o * 16 + i] = acc[i] + bias_reg(bias[o & 1], i);
+            [&](auto mm, const f32x16 (&acc)[NOB_OUT]) {
+                prev_slot(mm);
+                if constexpr (NOB_OUT > 1) {          // finished output blocks: plain bias add
+                    constexpr LayerGeom GO = layer_geom(NB * 16, NOB_OUT);
+                    constexpr int M = decltype(mm)::value;
+                    constexpr int id = act_group_at(GO, M, 0);
+                    if constexpr (id >= 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            constexpr int blk = id / 4, r0 = 4 * (id % 4);
+                            net[blk * 16 + r0 + i] = acc[blk][r0 + i] + bias1(bias[blk & 1], r0 + i);
+                        }
+                    }
+                }
             },
             [&](const f32x16& acc) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) net[(NOB_OUT - 1) * 16 + r] = acc[r] + bias_reg(bias[(NOB_OUT - 1) & 1], r);
-            });
+                for (int r = 0; r < 16; ++r) net[(NOB_OUT - 1) * 16 + r] = acc[r] + bias1(bias[(NOB_OUT - 1) & 1], r);
+            },
+            dbg);
 
         // ---- RHS and stage bookkeeping -----------------------------------------------------
         float rhs[DREGS];
