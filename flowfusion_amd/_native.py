@@ -35,7 +35,7 @@ class PlanStruct(ctypes.Structure):
         ("dregs", ctypes.c_int32),
         ("cregs", ctypes.c_int32),
         ("kernel_id", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("tile", ctypes.c_int32),
     ]
 
 
@@ -115,8 +115,8 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int) -> PlanStru
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}: "
-            "compiled shapes cover dim<=32, cond_dim<=16, hidden width<=256 "
-            "(exact-trace mode additionally needs dim<=31)")
+            "compiled shapes cover dim<=32 / cond_dim<=16 / hidden width<=256 (32x32x2 kernels) and "
+            "dim<=64 / cond_dim<=16 / width<=512 (16x16x4 kernels); exact-trace mode needs dim+1 <= tile")
     if rc != FF_OK:
         raise _err(rc, "ff_mlp_plan")
     return p

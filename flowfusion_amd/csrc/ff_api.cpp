@@ -1,6 +1,7 @@
 // ff_api.cpp -- C ABI of libflowfusion_amd.so (see include/flowfusion_amd.h).
 #include <hip/hip_runtime_api.h>
 #include <string.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include "flowfusion_amd.h"
 #include "ff_layout.h"
@@ -45,17 +46,22 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
         if (hidden_widths[i] < 1) return FF_ERR_BADARG;
         if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
     }
-    const int need_d = ff::regs_for(dim);
-    const int need_c = cond_dim > 0 ? ff::regs_for(cond_dim) : 0;
     const int need_t = mode != FF_MODE_STATE;
+    const char* force16 = getenv("FF_FORCE_TILE16");      // experiments: prefer the 16x16x4 kernels
     int best = -1;
     for (int i = 0; i < ff::g_n_kernels; ++i) {
         const ff::KernelEntry& k = ff::g_kernels[i];
+        const int need_d = ff::regs_for(k.tile, dim);
+        const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
         if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t) continue;
+        if (mode == FF_MODE_EXACT && dim + 1 > k.tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
-        // cheapest first: width dominates the FLOPs, then the first-layer k-steps
-        if (k.H < b.H || (k.H == b.H && (k.dregs + k.cregs < b.dregs + b.cregs))) best = i;
+        // cheapest first: width dominates the FLOPs; then the wider tile (fewer weight bytes per
+        // sample); then the first-layer k-steps
+        const bool pref_tile = force16 ? (k.tile < b.tile) : (k.tile > b.tile);
+        if (k.H < b.H || (k.H == b.H && (pref_tile || (k.tile == b.tile && k.dregs + k.cregs < b.dregs + b.cregs))))
+            best = i;
     }
     if (best < 0) return FF_ERR_UNSUPPORTED;
     memset(plan, 0, sizeof(*plan));
@@ -66,6 +72,7 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
     plan->dregs = ff::g_kernels[best].dregs;
     plan->cregs = ff::g_kernels[best].cregs;
     plan->kernel_id = best;
+    plan->tile = ff::g_kernels[best].tile;
     return FF_OK;
 }
 
@@ -73,14 +80,20 @@ static bool plan_ok(const ff_mlp_plan_t* p)
 {
     if (!p || p->kernel_id < 0 || p->kernel_id >= ff::g_n_kernels) return false;
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
-    return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && p->n_hidden >= 1 &&
-           p->dim >= 1 && p->dim <= 2 * p->dregs && p->cond_dim >= 0 && p->cond_dim <= 2 * p->cregs;
+    const int per_reg = 64 / k.tile;
+    return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
+           p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
+}
+
+static ff::Layout plan_layout(const ff_mlp_plan_t* p)
+{
+    return ff::make_layout(p->tile, p->width, p->dregs, p->cregs, p->n_hidden);
 }
 
 extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
 {
     if (!plan_ok(plan)) return 0;
-    return ff::make_layout(plan->width, plan->dregs, plan->cregs, plan->n_hidden).total_floats;
+    return plan_layout(plan).total_floats;
 }
 
 extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
@@ -94,7 +107,8 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
         if (hidden_widths[i] < 1 || hidden_widths[i] > H) return FF_ERR_BADARG;
     for (int i = 0; i <= NH; ++i)
         if (!W[i] || (i > 0 && !b[i])) return FF_ERR_BADARG;
-    const ff::Layout L = ff::make_layout(H, plan->dregs, plan->cregs, NH);
+    const ff::Layout L = plan_layout(plan);
+    const int TL = plan->tile, PHYS = ff::tile_phys(TL), CF = L.chunk_fl;
     memset(out, 0, L.total_floats * sizeof(float));
 
     // Fill the chunks of one layer in consumption order (ff_layout.h).  `kcol(r, h)` maps operand
@@ -102,28 +116,30 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
     auto fill = [&](const ff::LayerGeom& G, float* o, const float* Wl, int rows, int ld, auto kcol) {
         for (int c = 0; c < G.NC; ++c) {
             const int g = ff::chunk_group(G, c), ob = ff::chunk_block(G, c);
-            for (int lane = 0; lane < 64; ++lane)
-                for (int q = 0; q < 4; ++q) {
-                    const int row = ob * 32 + (lane & 31);
-                    const int col = kcol(4 * g + q, lane >> 5);
-                    o[((size_t)c * 64 + lane) * 4 + q] = (row < rows && col >= 0) ? Wl[(size_t)row * ld + col] : 0.f;
-                }
+            for (int p = 0; p < PHYS; ++p)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = ob * 32 + TL * p + (lane & (TL - 1));
+                        const int col = kcol(4 * g + q, lane / TL);
+                        o[(size_t)c * CF + ((size_t)p * 64 + lane) * 4 + q] =
+                            (row < rows && col >= 0) ? Wl[(size_t)row * ld + col] : 0.f;
+                    }
         }
     };
     // first layer: operand registers = [state | conditional]
     fill(L.g1, out, W[0], hidden_widths[0], in_features0, [&](int r, int h) {
         if (r < plan->dregs) {
-            const int d = ff::feat_of_reg(r, h);
+            const int d = ff::feat_of_reg(TL, r, h);
             return d < D ? x_col0 + d : -1;
         }
-        const int d = ff::feat_of_reg(r - plan->dregs, h);
+        const int d = ff::feat_of_reg(TL, r - plan->dregs, h);
         return d < C ? c_col0 + d : -1;
     });
     // hidden -> hidden
     for (int l = 1; l < NH; ++l) {
         const int win = hidden_widths[l - 1], wout = hidden_widths[l];
-        fill(L.gh, out + (size_t)L.chunk_off_hid(l - 1) * ff::kChunkFloats, W[l], wout, win, [&](int r, int h) {
-            const int k = ff::feat_of_reg(r, h);
+        fill(L.gh, out + (size_t)L.chunk_off_hid(l - 1) * CF, W[l], wout, win, [&](int r, int h) {
+            const int k = ff::feat_of_reg(TL, r, h);
             return k < win ? k : -1;
         });
         float* bo = out + L.bias_off_hid(l - 1);
@@ -132,8 +148,8 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
     // output layer
     {
         const int win = hidden_widths[NH - 1];
-        fill(L.go, out + (size_t)L.chunk_off_out() * ff::kChunkFloats, W[NH], D, win, [&](int r, int h) {
-            const int k = ff::feat_of_reg(r, h);
+        fill(L.go, out + (size_t)L.chunk_off_out() * CF, W[NH], D, win, [&](int r, int h) {
+            const int k = ff::feat_of_reg(TL, r, h);
             return k < win ? k : -1;
         });
         float* bo = out + L.bias_off_out();
@@ -148,7 +164,7 @@ extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
     int nt, unit;
     int rc = tangents_of_mode(mode, plan->dim, &nt, &unit);
     if (rc) return rc;
-    return 4 * (32 / (1 + nt));
+    return 4 * (plan->tile / (1 + nt));
 }
 
 extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
@@ -174,12 +190,13 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
     ka.n_tangent = nt; ka.unit_tangents = unit;
     ka.etab_stride = FF_ROW_HDR + plan->width;
-    const ff::Layout L = ff::make_layout(plan->width, plan->dregs, plan->cregs, plan->n_hidden);
+    const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     if ((size_t)a->n_evals * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     ka.wpack_floats = (int)L.total_floats;
 
-    const long long spw = 4ll * (32 / (1 + nt));
+    if (a->mode == FF_MODE_EXACT && plan->dim + 1 > plan->tile) return FF_ERR_UNSUPPORTED;
+    const long long spw = 4ll * (plan->tile / (1 + nt));
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
     const unsigned lds = 4u * ff::kSlots * (plan->dregs / 4) * 64 * 16;

@@ -1,31 +1,32 @@
 // ff_layout.h -- tiling shared by the host-side weight packer and the gfx950 kernels.
 //
-// Geometry (one wavefront = 64 lanes, v_mfma_f32_32x32x2_f32):
-//   * samples (and tangent columns) sit on the MFMA column index  col  = lane & 31;
-//   * features sit on the MFMA row index; an accumulator tile of 32 rows x 32 columns
-//     is 16 registers per lane, register q of lane-half h = lane >> 5 holding row
-//         rho(q, h) = (q & 3) + 8 * (q >> 2) + 4 * h                     (CDNA4 C/D map)
-//   * a vector of F features per column is therefore F/2 registers per lane; register
-//     r holds feature  feat(r, h) = 32 * (r >> 4) + rho(r & 15, h).
-//   * the B operand of the f32 MFMA is one register per lane: lanes 0-31 give k = 0,
-//     lanes 32-63 give k = 1.  Feeding activation register r straight back as B means
-//     this k-step contracts over the feature pair { feat(r,0), feat(r,1) } -- so the
-//     accumulator of one layer IS the operand of the next, with no data movement, as
-//     long as the A operand (the weights) is packed in the matching order.  That
-//     packing is what this header defines.
+// Two f32 MFMA shapes are used (TILE = columns = samples per wavefront):
+//   TILE 32: v_mfma_f32_32x32x2_f32   lane group q = lane>>5 in {0,1};   K per MFMA = 2
+//   TILE 16: v_mfma_f32_16x16x4_f32   lane group q = lane>>4 in {0..3};  K per MFMA = 4
+// Samples (and tangent columns) sit on the MFMA column index  col = lane & (TILE-1); features on
+// the row index.  The accumulator tile holds, in register i of lane group q, row
+//     TILE 32:  (i & 3) + 8 * (i >> 2) + 4 * q      (16 registers, CDNA4 C/D map)
+//     TILE 16:  (i & 3) + 4 * q                       ( 4 registers)
+// A vector of F features per column is F / NQ registers per lane (NQ = 64 / TILE lane groups);
+// register r of group q holds feature feat(r, q) below, where RB = registers per LOGICAL BLOCK of
+// 32 feature rows (16 for TILE 32; 8 for TILE 16 = two 16-row accumulator tiles).  The B operand
+// of the f32 MFMA is one register per lane whose lane group q supplies k = q, so feeding
+// activation register r straight back as B contracts over the features { feat(r, q) } -- the
+// accumulator of one layer IS the operand of the next, with no data movement, as long as the A
+// operand (the weights) is packed in the matching order.
 //
-// A operands are stored as CHUNKS of 1 KiB: 64 lanes x 4 floats; lane l, float q of the chunk
-// for (group g, output block ob) of a layer is
-//       W[ ob*32 + (l & 31) ][ kcol(4*g + q, l >> 5) ]
-// so one 16-byte load per lane feeds 4 MFMAs.  The chunks of one evaluation form a single
-// linear stream in the exact order the kernel consumes them (layer 1, hidden layers, output
-// layer), which lets the kernel prefetch with one uniform sliding window, across layer and
-// evaluation boundaries.  Within a layer of G groups and NOB blocks the order is
+// A operands are stored as CHUNKS: for (group g of 4 operand registers, logical block ob), PHYS
+// sub-chunks of 1 KiB (PHYS = 32 / TILE accumulator tiles per logical block); sub-chunk p, lane l,
+// float j  =  W[ 32*ob + TILE*p + (l & (TILE-1)) ][ kcol(4*g + j, l / TILE) ]
+// so one 16-byte load per lane feeds 4 MFMAs.  The chunks of one evaluation form a single linear
+// stream in the exact order the kernel consumes them (layer 1, hidden layers, output layer), which
+// lets the kernel prefetch with one uniform sliding window across layer and evaluation
+// boundaries.  Within a layer of G groups and NOB logical blocks the order is
 //   phase A (groups 0 .. G-5): group-major  -- all NOB accumulators advance together;
 //   phase B (last min(G,4) groups): block-major -- accumulator ob completes after its last
-//           chunk, so its activation overlaps the MFMAs of block ob+1.
-// Each layer's chunk count is padded to a multiple of kChunkPad (zero chunks, loaded but
-// unused) so the prefetch ring position is a compile-time constant everywhere.
+//           chunk, so its activation can run behind the MFMAs of block ob+1.
+// Each layer's chunk count is padded to a multiple of kChunkPad (zero chunks, loaded but unused)
+// so the prefetch ring position is a compile-time constant everywhere.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -38,22 +39,35 @@
 
 namespace ff {
 
-constexpr int kChunkFloats = 256;   // 1 KiB
-constexpr int kChunkPad = 16;       // layer chunk counts are padded to a multiple of this
+constexpr int kSubChunkFloats = 256;  // 1 KiB: 64 lanes x 16 bytes
+constexpr int kChunkPad = 16;         // layer chunk counts are padded to a multiple of this
 
-// feature index held by activation/state register r on lane-half h
-FF_HD constexpr int feat_of_reg(int r, int h) { return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h; }
+FF_HD constexpr int tile_nq(int tile) { return 64 / tile; }          // lane groups
+FF_HD constexpr int tile_phys(int tile) { return 32 / tile; }        // accumulator tiles per logical block
+FF_HD constexpr int tile_rb(int tile) { return 32 / tile_nq(tile); } // registers per logical block (16 / 8)
+FF_HD constexpr int chunk_floats(int tile) { return kSubChunkFloats * tile_phys(tile); }
 
-// number of lane registers needed for F features (multiple of 4 registers = 8 features)
-FF_HD constexpr int regs_for(int F) { return 4 * ((F + 7) / 8); }
+// feature index held by activation/state register r on lane group q
+FF_HD constexpr int feat_of_reg(int tile, int r, int q)
+{
+    return tile == 32 ? 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * q
+                      : 32 * (r >> 3) + 16 * ((r & 7) >> 2) + 4 * q + (r & 3);
+}
 
-// output blocks (32 rows) needed to produce `regs` registers
-FF_HD constexpr int blocks_for_regs(int regs) { return (regs + 15) / 16; }
+// number of lane registers needed for F features (multiple of 4 registers)
+FF_HD constexpr int regs_for(int tile, int F)
+{
+    const int per4 = 4 * tile_nq(tile);      // features covered by 4 registers
+    return 4 * ((F + per4 - 1) / per4);
+}
 
-// Chunk order of one layer with KR operand registers and NOB output blocks.
+// logical output blocks (32 rows) needed to produce `regs` registers
+FF_HD constexpr int blocks_for_regs(int tile, int regs) { return (regs + tile_rb(tile) - 1) / tile_rb(tile); }
+
+// Chunk order of one layer with KR operand registers and NOB logical output blocks.
 struct LayerGeom {
-    int G;      // groups of 4 k-steps
-    int NOB;    // output blocks
+    int G;      // groups of 4 operand registers
+    int NOB;    // logical output blocks
     int GB;     // groups in phase B (block-major tail)
     int GA;     // groups in phase A (group-major)
     int NC;     // real chunks = G * NOB
@@ -77,30 +91,25 @@ FF_HD constexpr int chunk_group(const LayerGeom& L, int c)
 {
     return c < L.GA * L.NOB ? c / L.NOB : L.GA + (c - L.GA * L.NOB) % L.GB;
 }
-// chunk index -> output block
+// chunk index -> logical output block
 FF_HD constexpr int chunk_block(const LayerGeom& L, int c)
 {
     return c < L.GA * L.NOB ? c % L.NOB : (c - L.GA * L.NOB) / L.GB;
 }
-// true if chunk c is the last one that touches its output block
-FF_HD constexpr bool chunk_completes_block(const LayerGeom& L, int c)
-{
-    return c >= L.GA * L.NOB && (c - L.GA * L.NOB) % L.GB == L.GB - 1;
-}
 
 struct Layout {
+    int tile;     // 32 or 16
     int H;        // hidden width on chip (multiple of 32)
-    int NB;       // H / 32
+    int NB;       // H / 32 logical blocks
     int dregs;    // state registers
     int cregs;    // conditional registers
     int n_hidden; // hidden layers
-    int nob_out;  // output blocks of the last layer
+    int nob_out;  // logical output blocks of the last layer
     LayerGeom g1, gh, go;   // first layer, hidden->hidden, output layer
 
-    // chunk stream (in chunks)
-    int chunks_l1, chunks_hid, chunks_out, chunks_total;
-    // sizes in floats
-    size_t stream_floats;   // chunks_total * 256
+    int chunks_l1, chunks_hid, chunks_out, chunks_total;   // chunk stream (in chunks)
+    int chunk_fl;           // floats per chunk
+    size_t stream_floats;   // chunks_total * chunk_fl
     size_t bias_floats;     // (n_hidden-1) * H + nob_out*32
     size_t total_floats;
 
@@ -110,19 +119,20 @@ struct Layout {
     FF_HD size_t bias_off_out() const { return stream_floats + (size_t)(n_hidden - 1) * H; }
 };
 
-FF_HD constexpr Layout make_layout(int H, int dregs, int cregs, int n_hidden)
+FF_HD constexpr Layout make_layout(int tile, int H, int dregs, int cregs, int n_hidden)
 {
     Layout L{};
-    L.H = H; L.NB = H / 32; L.dregs = dregs; L.cregs = cregs; L.n_hidden = n_hidden;
-    L.nob_out = blocks_for_regs(dregs);
+    L.tile = tile; L.H = H; L.NB = H / 32; L.dregs = dregs; L.cregs = cregs; L.n_hidden = n_hidden;
+    L.nob_out = blocks_for_regs(tile, dregs);
     L.g1 = layer_geom(dregs + cregs, L.NB);
-    L.gh = layer_geom(L.NB * 16, L.NB);
-    L.go = layer_geom(L.NB * 16, L.nob_out);
+    L.gh = layer_geom(H / tile_nq(tile), L.NB);
+    L.go = layer_geom(H / tile_nq(tile), L.nob_out);
     L.chunks_l1 = L.g1.CPAD;
     L.chunks_hid = L.gh.CPAD;
     L.chunks_out = L.go.CPAD;
     L.chunks_total = L.chunks_l1 + (n_hidden - 1) * L.chunks_hid + L.chunks_out;
-    L.stream_floats = (size_t)L.chunks_total * kChunkFloats;
+    L.chunk_fl = chunk_floats(tile);
+    L.stream_floats = (size_t)L.chunks_total * L.chunk_fl;
     L.bias_floats = (size_t)(n_hidden - 1) * H + (size_t)L.nob_out * 32;
     L.total_floats = L.stream_floats + L.bias_floats;
     return L;

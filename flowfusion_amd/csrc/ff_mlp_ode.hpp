@@ -29,8 +29,8 @@ namespace ff {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRing = 8;    // weight chunks (1 KiB each, 4 VGPRs per lane) kept in flight per wavefront
-static_assert(kChunkPad % kRing == 0, "ring must divide the chunk padding");
+// RING (template parameter below) = weight chunks kept in flight per wavefront; it must divide
+// kChunkPad so that every layer starts at ring slot 0.
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
@@ -42,11 +42,6 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
 // sigmoid from the hardware exp2 / rcp units (each within 1 ulp): silu(a) = a*s,
@@ -74,15 +69,55 @@ __device__ __forceinline__ f32x4 sload(const Stream& s, int voff, int soff)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, voff, soff, 0));
 }
 
-// 32 bias rows of one output block in accumulator-register order (4 x 16 bytes per lane half)
-struct Bias16 {
-    f32x4 v[4];
+// MFMA shape traits: one LOGICAL block = 32 feature rows = PHYS accumulator tiles.
+template <int TILE>
+struct Tile;
+template <>
+struct Tile<32> {
+    static constexpr int NQ = 2, PHYS = 1, RB = 16, SHIFT = 5;
+    typedef f32x16 Vec;
+    static __device__ __forceinline__ Vec zero()
+    {
+        return Vec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ Vec mfma(float a, float b, Vec c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
 };
-__device__ __forceinline__ Bias16 load_bias(const Stream& s, int half16, int byte_off)
+template <>
+struct Tile<16> {
+    static constexpr int NQ = 4, PHYS = 2, RB = 8, SHIFT = 4;
+    typedef f32x4 Vec;
+    static __device__ __forceinline__ Vec zero() { return Vec{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ Vec mfma(float a, float b, Vec c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+// accumulators of one logical block; reg(r) = logical register r in [0, RB)
+template <int TILE>
+struct BlockAcc {
+    typename Tile<TILE>::Vec v[Tile<TILE>::PHYS];
+    __device__ __forceinline__ float reg(int r) const
+    {
+        if constexpr (TILE == 32) return v[0][r];
+        else return v[r >> 2][r & 3];
+    }
+};
+
+// bias rows of one logical block in accumulator-register order (RB/4 x 16 bytes per lane group)
+template <int TILE>
+struct BiasBlk {
+    f32x4 v[Tile<TILE>::RB / 4];
+    __device__ __forceinline__ float reg(int r) const { return v[r >> 2][r & 3]; }
+};
+template <int TILE>
+__device__ __forceinline__ BiasBlk<TILE> load_bias(const Stream& s, int q16, int byte_off)
 {
-    Bias16 b;
+    BiasBlk<TILE> b;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b.v[j] = sload(s, half16, byte_off + 32 * j);
+    for (int j = 0; j < Tile<TILE>::RB / 4; ++j) b.v[j] = sload(s, q16, byte_off + 16 * Tile<TILE>::NQ * j);
     return b;
 }
 
@@ -123,6 +158,7 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
     }
 }
 constexpr int kActStages = 5;
+constexpr int kTailSlots = 2 * kActStages;   // slots granted after a layer's last MFMA
 
 #ifdef FF_DEBUG_STAMPS
 // Diagnostic build: cycle stamps (s_memtime) of wavefront 0, written to a buffer nothing else reads.
@@ -138,57 +174,65 @@ __device__ __forceinline__ void ff_stamp(unsigned long long* buf, int& n, bool o
 #endif
 
 // One layer:  acc[ob] = W[ob,:] . B  over the layer's chunk stream, consumed in the order of
-// ff_layout.h.  `ring` holds the next kRing chunks on entry and on exit (of the following
-// layer); chunk c + kRing is requested right after chunk c's four MFMAs have been issued.
+// ff_layout.h.  `ring` holds the next RING chunks on entry and on exit (of the following
+// layer); chunk c + RING is requested right after chunk c's MFMAs have been issued.  With
+// TILE 16 a chunk feeds two accumulator tiles whose MFMAs alternate, which also keeps dependent
+// MFMAs (40-cycle latency, 32-cycle issue) from following each other directly.
 //
 //   sbyte          byte offset of this layer's chunk 0 in the stream (wave-uniform)
 //   WRAP           the stream ends with this layer: prefetch wraps to offset 0 (next evaluation)
 //   pre_block(ob)  called at the first phase-B chunk of block ob (bias prefetch)
-//   slot(M, acc)   called after the M-th MFMA of the layer has been issued, and kActStages more
+//   slot(M, acc)   called after the M-th MFMA of the layer has been issued, and kTailSlots more
 //                  times after the last one: the caller hangs the activation stages of finished
-//                  blocks on these slots so that VALU work runs in the shadow of the matrix pipe
+//                  blocks on these slots
 //   last(acc)      called once the last block's accumulator is complete
-template <int KR, int NOB, bool WRAP, class PreFn, class SlotFn, class LastFn, class DbgFn>
-__device__ __forceinline__ void run_layer(f32x4 (&ring)[kRing], const Stream& ws, int lane16, int sbyte,
-                                          const float (&B)[KR], PreFn&& pre_block, SlotFn&& slot_fn,
+template <int TILE, int RING, int KR, int NOB, bool WRAP, class PreFn, class SlotFn, class LastFn, class DbgFn>
+__device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS], const Stream& ws, int lane16,
+                                          int sbyte, const float (&B)[KR], PreFn&& pre_block, SlotFn&& slot_fn,
                                           LastFn&& last, DbgFn&& dbg)
 {
+    typedef Tile<TILE> T;
     constexpr LayerGeom L = layer_geom(KR, NOB);
-    f32x16 acc[NOB];
+    constexpr int CB = 1024 * T::PHYS;              // bytes per chunk
+    BlockAcc<TILE> acc[NOB];
     dbg();
     static_for<L.CPAD>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        constexpr int slot = c % kRing;
+        constexpr int slot = c % RING;
         if constexpr (c == L.GA * L.NOB && c > 0) dbg();
         if constexpr (c < L.NC) {
             constexpr int g = chunk_group(L, c);
             constexpr int ob = chunk_block(L, c);
             constexpr bool phase_b = c >= L.GA * L.NOB;
             if constexpr (phase_b && (c - L.GA * L.NOB) % L.GB == 0) pre_block(std::integral_constant<int, ob>{});
-            const f32x4 a = ring[slot];
             static_for<4>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                if constexpr (g == 0 && q == 0)
-                    acc[ob] = mfma32(a[q], B[4 * g + q], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
-                                                                 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                else
-                    acc[ob] = mfma32(a[q], B[4 * g + q], acc[ob]);
-                slot_fn(std::integral_constant<int, 4 * c + q>{}, acc);
+                static_for<T::PHYS>([&](auto pp) {
+                    constexpr int p = decltype(pp)::value;
+                    if constexpr (g == 0 && q == 0)
+                        acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], T::zero());
+                    else
+                        acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], acc[ob].v[p]);
+                    slot_fn(std::integral_constant<int, (4 * c + q) * T::PHYS + p>{}, acc);
+                });
             });
             if constexpr (c == L.NC - 1) {
                 dbg();
                 last(acc[NOB - 1]);
-                static_for<kActStages>([&](auto tt) {
-                    slot_fn(std::integral_constant<int, 4 * L.NC + decltype(tt)::value>{}, acc);
+                static_for<kTailSlots>([&](auto tt) {
+                    slot_fn(std::integral_constant<int, 4 * L.NC * T::PHYS + decltype(tt)::value>{}, acc);
                 });
                 dbg();
             }
         }
-        constexpr int nxt = c + kRing;
-        if constexpr (WRAP && nxt >= L.CPAD)
-            ring[slot] = sload(ws, lane16, (nxt - L.CPAD) * 1024);
-        else
-            ring[slot] = sload(ws, lane16, sbyte + nxt * 1024);
+        constexpr int nxt = c + RING;
+        static_for<T::PHYS>([&](auto pp) {
+            constexpr int p = decltype(pp)::value;
+            if constexpr (WRAP && nxt >= L.CPAD)
+                ring[slot][p] = sload(ws, lane16, (nxt - L.CPAD) * CB + p * 1024);
+            else
+                ring[slot][p] = sload(ws, lane16, sbyte + nxt * CB + p * 1024);
+        });
         // Pin the stream order: MFMAs and vector-memory loads may not be scheduled across this
         // point (VALU / SALU / transcendental / DS work of the activations may), so every load
         // is issued exactly one ring length ahead of its use.
@@ -201,33 +245,41 @@ struct GeomTag {
     static constexpr LayerGeom value = layer_geom(KR, NOB);
 };
 
-// Activation schedule of a layer with geometry L: group gi (4 registers) of block blk (< NOB-1)
-// starts its stages at MFMA slot  pb + (blk+1)*4*GB + gi*GB  (pb = first phase-B MFMA), i.e. as soon
-// as block blk+1 has started -- its accumulator is then complete.  Returns the flat group id
-// (blk*4 + gi) whose stage `k` falls on slot M, or -1.
-FF_HD constexpr int act_group_at(const LayerGeom& L, int M, int k)
+// Activation schedule.  A logical block has GPB = RB/4 groups of 4 registers and spans
+// SPB = 4*GB*PHYS MFMA slots in phase B.  Group gi of block blk (< NOB-1) starts its stages at slot
+//     pb + (blk+1)*SPB + gi*(SPB/GPB)          (pb = first phase-B slot)
+// i.e. once block blk+1 has started and its own accumulator is complete; stage k follows k*PHYS
+// slots (one 64-cycle MFMA time) later.  Returns the flat group id blk*GPB + gi whose stage k falls
+// on slot M, or -1.
+FF_HD constexpr int act_group_at(const LayerGeom& L, int phys, int gpb, int M, int k)
 {
-    const int s0 = M - 4 * L.GA * L.NOB - k;
-    if (s0 < 4 * L.GB || s0 % L.GB != 0) return -1;
-    const int q = s0 / L.GB;
-    const int blk = q / 4 - 1, gi = q % 4;
-    return blk <= L.NOB - 2 ? blk * 4 + gi : -1;
+    const int spb = 4 * L.GB * phys, step = spb / gpb;
+    const int s0 = M - 4 * L.GA * L.NOB * phys - k * phys;
+    if (s0 < spb || s0 % step != 0) return -1;
+    const int q = s0 / step;
+    const int blk = q / gpb - 1, gi = q % gpb;
+    return blk <= L.NOB - 2 ? blk * gpb + gi : -1;
 }
 
-template <int H, int DREGS, int CREGS, bool TANGENTS>
-__global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
+template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING>
+__global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args)
 {
-    constexpr int NB = H / 32;
-    constexpr int NOB_OUT = (DREGS + 15) / 16;
+    static_assert(kChunkPad % RING == 0, "ring must divide the chunk padding");
+    typedef Tile<TILE> T;
+    constexpr int NB = H / 32;                       // logical blocks per hidden layer
+    constexpr int RB = T::RB;                        // registers per logical block
+    constexpr int GPB = RB / 4;                      // activation groups per logical block
+    constexpr int NOB_OUT = blocks_for_regs(TILE, DREGS);
     constexpr int K1 = DREGS + CREGS;
+    constexpr int KH = NB * RB;                      // operand registers of a hidden layer
     constexpr int R4 = DREGS / 4;
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;   // scalar (SMEM) loads
 
     const int lane = threadIdx.x & 63;
-    const int half = lane >> 5;
-    const int col = lane & 31;
+    const int qd = lane >> T::SHIFT;                 // lane group (k index of the MFMA operands)
+    const int col = lane & (TILE - 1);
     const int lane16 = lane * 16;
-    const int half16 = half * 16;
+    const int q16 = qd * 16;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int D = args.dim;
     const int C = args.cond_dim;
@@ -240,15 +292,15 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     int value_lane_bytes = lane * 4;
     if constexpr (TANGENTS) {
         const int ncol = 1 + args.n_tangent;
-        const int samples_per_wave = 32 / ncol;
+        const int samples_per_wave = TILE / ncol;
         int s_in_wave = col / ncol;
         role = col - s_in_wave * ncol;
         if (s_in_wave >= samples_per_wave) { s_in_wave = 0; role = 0; col_live = false; }
         is_tangent = role != 0;
-        value_lane_bytes = ((half << 5) | (s_in_wave * ncol)) * 4;
+        value_lane_bytes = ((qd << T::SHIFT) | (s_in_wave * ncol)) * 4;
         sample = wave * samples_per_wave + s_in_wave;
     } else {
-        sample = wave * 32 + col;
+        sample = wave * TILE + col;
     }
     if (sample >= args.batch) { sample = args.batch - 1; col_live = false; }
 
@@ -256,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     float x[DREGS];
 #pragma unroll
     for (int r = 0; r < DREGS; ++r) {
-        const int d = feat_of_reg(r, half);
+        const int d = feat_of_reg(TILE, r, qd);
         float v = 0.f;
         if (d < D) {
             if (!is_tangent) {
@@ -275,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     if constexpr (CREGS > 0) {
 #pragma unroll
         for (int r = 0; r < CREGS; ++r) {
-            const int d = feat_of_reg(r, half);
+            const int d = feat_of_reg(TILE, r, qd);
             cnd[r] = (d < C && !is_tangent) ? args.cond[sample * C + d] : 0.f;
         }
     }
@@ -300,18 +352,21 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
     for (int s = 0; s < kSlots; ++s) kl[s] = 0.f;
     float lp = 0.f;
 
-    const Layout L = make_layout(H, DREGS, CREGS, args.n_hidden);
+    const Layout L = make_layout(TILE, H, DREGS, CREGS, args.n_hidden);
+    constexpr int CB = 1024 * T::PHYS;               // bytes per chunk
     const Stream ws = make_stream(args.wpack, args.wpack_floats);
     const Stream ts = make_stream(args.etab, (long long)args.n_evals * args.etab_stride);
-    const int out_sbyte = L.chunk_off_out() * 1024;
+    const int out_sbyte = L.chunk_off_out() * CB;
     const int out_bias_byte = (int)(L.bias_off_out() * 4);
 
-    // prefetch ring: the first kRing chunks of layer 1
-    f32x4 ring[kRing];
+    // prefetch ring: the first RING chunks of layer 1
+    f32x4 ring[RING][T::PHYS];
 #pragma unroll
-    for (int i = 0; i < kRing; ++i) ring[i] = sload(ws, lane16, i * 1024);
+    for (int i = 0; i < RING; ++i)
+#pragma unroll
+        for (int p = 0; p < T::PHYS; ++p) ring[i][p] = sload(ws, lane16, i * CB + p * 1024);
 
-    float P[NB * 16];
+    float P[KH];
 #ifdef FF_DEBUG_STAMPS
     int stamp_n = 0;
     const bool stamp_on = (blockIdx.x == 0 && threadIdx.x == 0 && args.debug_stamps != nullptr);
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
             const float* np = args.noise + (size_t)hdr->noise_idx * args.noise_stride + sample * D;
 #pragma unroll
             for (int r = 0; r < DREGS; ++r) {
-                const int d = feat_of_reg(r, half);
+                const int d = feat_of_reg(TILE, r, qd);
                 nz[r] = (d < D) ? np[d] : 0.f;
             }
         }
@@ -357,107 +412,109 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
         auto dbg = []() {};
 #endif
         // `pend` = pre-activations (accumulator + bias) of the previous layer's last block; they
-        // are activated into P[(NB-1)*16 ..] behind the first MFMAs of the next layer, whose
+        // are activated into P[(NB-1)*RB ..] behind the first MFMAs of the next layer, whose
         // phase A does not read the last k-block.
-        float pend[16];
-        Bias16 bias[2];
+        float pend[RB];
+        BiasBlk<TILE> bias[2];
         ActGroup ag[12];         // in-flight groups: [0,4) parked block of the previous layer, 4 + id % 8 own blocks
-        auto bias1 = [&](const Bias16& b, int r) {
-            const float v = b.v[r >> 2][r & 3];
+        auto bias1 = [&](const BiasBlk<TILE>& b, int r) {
+            const float v = b.reg(r);
             return TANGENTS ? (is_tangent ? 0.f : v) : v;
         };
-        // stages of the previous layer's parked block: group gi starts at slot 4*gi
+        // stages of the previous layer's parked block: group gi starts at slot gi*(16*PHYS/GPB)
         auto prev_slot = [&](auto mm) {
             constexpr int M = decltype(mm)::value;
             static_for<kActStages>([&](auto kk) {
                 constexpr int k = kActStages - 1 - decltype(kk)::value;     // oldest group first
-                constexpr int s0 = M - k;
-                if constexpr (s0 >= 0 && s0 < 16 && s0 % 4 == 0) {
-                    constexpr int gi = s0 / 4;
+                constexpr int step = 16 * T::PHYS / GPB;
+                constexpr int s0 = M - k * T::PHYS;
+                if constexpr (s0 >= 0 && s0 < 16 * T::PHYS && s0 % step == 0) {
+                    constexpr int gi = s0 / step;
                     if constexpr (k == 0) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ag[gi].pre[i] = pend[4 * gi + i];
                     }
-                    act_stage<TANGENTS, k>(ag[gi], &P[(NB - 1) * 16 + 4 * gi], is_tangent, value_lane_bytes);
+                    act_stage<TANGENTS, k>(ag[gi], &P[(NB - 1) * RB + 4 * gi], is_tangent, value_lane_bytes);
                 }
             });
         };
         // stages of this layer's own blocks 0 .. NB-2 (geometry G), hung on slot M
-        auto own_slot = [&](auto geom, auto mm, const f32x16 (&acc)[NB]) {
+        auto own_slot = [&](auto geom, auto mm, const BlockAcc<TILE> (&acc)[NB]) {
             constexpr LayerGeom G = decltype(geom)::value;
             constexpr int M = decltype(mm)::value;
             static_for<kActStages>([&](auto kk) {
                 constexpr int k = kActStages - 1 - decltype(kk)::value;     // oldest group first
-                constexpr int id = act_group_at(G, M, k);
+                constexpr int id = act_group_at(G, T::PHYS, GPB, M, k);
                 if constexpr (id >= 0) {
-                    constexpr int blk = id / 4, gi = id % 4;
+                    constexpr int blk = id / GPB, gi = id % GPB;
                     if constexpr (k == 0) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            ag[4 + id % 8].pre[i] = acc[blk][4 * gi + i] + bias1(bias[blk & 1], 4 * gi + i);
+                            ag[4 + id % 8].pre[i] = acc[blk].reg(4 * gi + i) + bias1(bias[blk & 1], 4 * gi + i);
                     }
-                    act_stage<TANGENTS, k>(ag[4 + id % 8], &P[blk * 16 + 4 * gi], is_tangent, value_lane_bytes);
+                    act_stage<TANGENTS, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes);
                 }
             });
         };
-        auto park_last = [&](const f32x16& acc) {
+        auto park_last = [&](const BlockAcc<TILE>& acc) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pend[r] = acc[r] + bias1(bias[(NB - 1) & 1], r);
+            for (int r = 0; r < RB; ++r) pend[r] = acc.reg(r) + bias1(bias[(NB - 1) & 1], r);
         };
         // ---- layer 1: [x | cond] -> H, bias c1_e ---------------------------------------
         {
             using G1 = GeomTag<K1, NB>;
-            run_layer<K1, NB, false>(
+            run_layer<TILE, RING, K1, NB, false>(
                 ring, ws, lane16, 0, y,
                 [&](auto ob) {
                     constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias(ts, half16, row_byte + 128 + o * 128);
+                    bias[o & 1] = load_bias<TILE>(ts, q16, row_byte + 128 + o * 128);
                 },
-                [&](auto mm, const f32x16 (&acc)[NB]) { own_slot(G1{}, mm, acc); }, park_last, dbg);
+                [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) { own_slot(G1{}, mm, acc); }, park_last, dbg);
         }
         // ---- hidden -> hidden ------------------------------------------------------------
         for (int l = 0; l < args.n_hidden - 1; ++l) {
-            using GH = GeomTag<NB * 16, NB>;
-            const int sbyte = L.chunk_off_hid(l) * 1024;
+            using GH = GeomTag<KH, NB>;
+            const int sbyte = L.chunk_off_hid(l) * CB;
             const int bbyte = (int)(L.bias_off_hid(l) * 4);
-            run_layer<NB * 16, NB, false>(
+            run_layer<TILE, RING, KH, NB, false>(
                 ring, ws, lane16, sbyte, P,
                 [&](auto ob) {
                     constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias(ws, half16, bbyte + o * 128);
+                    bias[o & 1] = load_bias<TILE>(ws, q16, bbyte + o * 128);
                 },
-                [&](auto mm, const f32x16 (&acc)[NB]) {
+                [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) {
                     prev_slot(mm);
                     own_slot(GH{}, mm, acc);
                 },
                 park_last, dbg);
         }
         // ---- output layer ----------------------------------------------------------------
-        float net[NOB_OUT * 16];
-        run_layer<NB * 16, NOB_OUT, true>(
+        float net[NOB_OUT * RB];
+        run_layer<TILE, RING, KH, NOB_OUT, true>(
             ring, ws, lane16, out_sbyte, P,
             [&](auto ob) {
                 constexpr int o = decltype(ob)::value;
-                bias[o & 1] = load_bias(ws, half16, out_bias_byte + o * 128);
+                bias[o & 1] = load_bias<TILE>(ws, q16, out_bias_byte + o * 128);
             },
-            [&](auto mm, const f32x16 (&acc)[NOB_OUT]) {
+            [&](auto mm, const BlockAcc<TILE> (&acc)[NOB_OUT]) {
                 prev_slot(mm);
                 if constexpr (NOB_OUT > 1) {          // finished output blocks: plain bias add
-                    constexpr LayerGeom GO = layer_geom(NB * 16, NOB_OUT);
+                    constexpr LayerGeom GO = layer_geom(KH, NOB_OUT);
                     constexpr int M = decltype(mm)::value;
-                    constexpr int id = act_group_at(GO, M, 0);
+                    constexpr int id = act_group_at(GO, T::PHYS, GPB, M, 0);
                     if constexpr (id >= 0) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            constexpr int blk = id / 4, r0 = 4 * (id % 4);
-                            net[blk * 16 + r0 + i] = acc[blk][r0 + i] + bias1(bias[blk & 1], r0 + i);
+                            constexpr int blk = id / GPB, r0 = 4 * (id % GPB);
+                            net[blk * RB + r0 + i] = acc[blk].reg(r0 + i) + bias1(bias[blk & 1], r0 + i);
                         }
                     }
                 }
             },
-            [&](const f32x16& acc) {
+            [&](const BlockAcc<TILE>& acc) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) net[(NOB_OUT - 1) * 16 + r] = acc[r] + bias1(bias[(NOB_OUT - 1) & 1], r);
+                for (int r = 0; r < RB; ++r)
+                    net[(NOB_OUT - 1) * RB + r] = acc.reg(r) + bias1(bias[(NOB_OUT - 1) & 1], r);
             },
             dbg);
 
@@ -505,21 +562,22 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_kernel(const KernelArgs args)
 
     // ---- epilogue -----------------------------------------------------------------------------
     if constexpr (TANGENTS) {
-        // sum the per-lane integrals over both lane halves and over the sample's tangent columns
+        // sum the per-lane integrals over all lane groups and over the sample's tangent columns
         float tot = 0.f;
         for (int j = 1; j <= args.n_tangent; ++j) {
-            const int src_lo = ((lane + j) & 63) * 4;
-            const int src_hi = (((lane ^ 32) + j) & 63) * 4;
-            tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lo, __builtin_bit_cast(int, lp)));
-            tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_hi, __builtin_bit_cast(int, lp)));
+#pragma unroll
+            for (int g = 0; g < T::NQ; ++g) {
+                const int src = ((g << T::SHIFT) | ((col + j) & (TILE - 1))) * 4;
+                tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp)));
+            }
         }
-        if (col_live && !is_tangent && half == 0 && args.dlogp_out) args.dlogp_out[sample] = tot;
+        if (col_live && !is_tangent && qd == 0 && args.dlogp_out) args.dlogp_out[sample] = tot;
     }
     bool bad = false;
     if (col_live && !is_tangent) {
 #pragma unroll
         for (int r = 0; r < DREGS; ++r) {
-            const int d = feat_of_reg(r, half);
+            const int d = feat_of_reg(TILE, r, qd);
             if (d < D) {
                 float v = x[r];
                 bad |= (v != v);

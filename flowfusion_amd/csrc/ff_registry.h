@@ -8,9 +8,10 @@ namespace ff {
 typedef int (*LaunchFn)(const KernelArgs* args, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 struct KernelEntry {
+    int tile;       // MFMA columns per wavefront: 32 (32x32x2) or 16 (16x16x4)
     int H;          // hidden width on chip
-    int dregs;      // state registers  (covers dim <= 2*dregs)
-    int cregs;      // conditional registers (covers cond_dim <= 2*cregs)
+    int dregs;      // state registers  (covers dim <= dregs * 64/tile)
+    int cregs;      // conditional registers
     int tangents;   // 1: divergence-capable instantiation
     LaunchFn launch;
     const char* name;

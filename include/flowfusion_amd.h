@@ -51,7 +51,7 @@ extern "C" {
 #define FF_ROW_HDR     32       /* 4-byte words in the header of one evaluation row        */
 
 /* mode flags for ff_ode_args.mode */
-#define FF_MODE_STATE      0    /* integrate the state only (32 samples per wavefront)     */
+#define FF_MODE_STATE      0    /* integrate the state only (`tile` samples per wavefront) */
 #define FF_MODE_HUTCH      1    /* state + Hutchinson divergence e^T J e in forward mode
                                    (16 samples + 16 tangent columns per wavefront)         */
 #define FF_MODE_EXACT      2    /* state + exact divergence tr J: `dim` unit tangents per
@@ -71,10 +71,10 @@ typedef struct ff_mlp_plan_t {
     int32_t cond_dim;    /* C  conditional inputs (0 = unconditional)                     */
     int32_t n_hidden;    /* number of hidden (Linear+SiLU) layers, >= 1                   */
     int32_t width;       /* common padded hidden width used on chip (multiple of 32)      */
-    int32_t dregs;       /* state registers per lane   = 4*ceil(D/8), padded to kernel    */
+    int32_t dregs;       /* state registers per lane, padded to the kernel's              */
     int32_t cregs;       /* conditional registers per lane                                */
     int32_t kernel_id;   /* index into the compiled instantiation table                   */
-    int32_t reserved;
+    int32_t tile;        /* MFMA columns per wavefront: 32 (32x32x2 f32) or 16 (16x16x4)  */
 } ff_mlp_plan_t;
 
 /* Arguments of one fused integration launch. */

@@ -9,8 +9,10 @@ GPU.  The lane-level MFMA mapping itself is only exercised by the `-m gpu` tests
 import torch
 
 
-def feat_of_reg(r, h):
-    return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h
+def feat_of_reg(tile, r, q):
+    if tile == 32:
+        return 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * q
+    return 32 * (r >> 3) + 16 * ((r & 7) >> 2) + 4 * q + (r & 3)
 
 
 def _geom(KR, NOB):
@@ -29,38 +31,43 @@ def _chunk_gob(L, c):
 
 
 def decode_wpack(plan, wpack):
-    """Invert the packing (csrc/ff_layout.h): dense zero-padded matrices W1[H, 2*dregs + 2*cregs],
-    hidden [H,H] + bias[H], output [nob_out*32, H] + bias."""
-    D, C, NH, H, dregs, cregs = plan[0], plan[1], plan[2], plan[3], plan[4], plan[5]
+    """Invert the packing (csrc/ff_layout.h): dense zero-padded matrices W1[H, dx + dc] (dx/dc =
+    feature capacity of the state / conditional registers), hidden [H,H] + bias[H], output
+    [nob_out*32, H] + bias."""
+    D, C, NH, H, dregs, cregs, tile = plan[0], plan[1], plan[2], plan[3], plan[4], plan[5], plan[7]
+    NQ, PHYS, RB = 64 // tile, 32 // tile, 32 // (64 // tile)
     NB = H // 32
-    nob_out = (dregs + 15) // 16
+    nob_out = (dregs + RB - 1) // RB
+    CF = 256 * PHYS
     w = wpack.double()
-    g1, gh, go = _geom(dregs + cregs, NB), _geom(NB * 16, NB), _geom(NB * 16, nob_out)
+    g1, gh, go = _geom(dregs + cregs, NB), _geom(H // NQ, NB), _geom(H // NQ, nob_out)
     stream = g1["CPAD"] + (NH - 1) * gh["CPAD"] + go["CPAD"]
+    dx, dc = dregs * NQ, cregs * NQ
 
     def decode(L, chunk0, kdim, kmap):
         M = torch.zeros(L["NOB"] * 32, kdim, dtype=torch.float64)
-        blk = w[chunk0 * 256:(chunk0 + L["CPAD"]) * 256].view(L["CPAD"], 64, 4)
+        blk = w[chunk0 * CF:(chunk0 + L["CPAD"]) * CF].view(L["CPAD"], PHYS, 64, 4)
         assert blk[L["NC"]:].abs().sum() == 0                    # padding chunks are zero
         for c in range(L["NC"]):
             g, ob = _chunk_gob(L, c)
-            for q in range(4):
-                for h in (0, 1):
-                    k = kmap(4 * g + q, h)
-                    M[ob * 32:(ob + 1) * 32, k] = blk[c, 32 * h:32 * h + 32, q]
+            for p in range(PHYS):
+                for j in range(4):
+                    for q in range(NQ):
+                        k = kmap(4 * g + j, q)
+                        M[ob * 32 + tile * p: ob * 32 + tile * (p + 1), k] = blk[c, p, tile * q: tile * (q + 1), j]
         return M
 
-    W1 = decode(g1, 0, 2 * dregs + 2 * cregs,
-                lambda r, h: feat_of_reg(r, h) if r < dregs else 2 * dregs + feat_of_reg(r - dregs, h))
+    W1 = decode(g1, 0, dx + dc,
+                lambda r, q: feat_of_reg(tile, r, q) if r < dregs else dx + feat_of_reg(tile, r - dregs, q))
     hidden = []
-    bias0 = stream * 256
+    bias0 = stream * CF
     for l in range(NH - 1):
-        Wl = decode(gh, g1["CPAD"] + l * gh["CPAD"], H, feat_of_reg)
+        Wl = decode(gh, g1["CPAD"] + l * gh["CPAD"], H, lambda r, q: feat_of_reg(tile, r, q))
         hidden.append((Wl, w[bias0 + l * H: bias0 + (l + 1) * H]))
-    Wo = decode(go, g1["CPAD"] + (NH - 1) * gh["CPAD"], H, feat_of_reg)
+    Wo = decode(go, g1["CPAD"] + (NH - 1) * gh["CPAD"], H, lambda r, q: feat_of_reg(tile, r, q))
     bo = w[bias0 + (NH - 1) * H: bias0 + (NH - 1) * H + nob_out * 32]
     assert bias0 + (NH - 1) * H + nob_out * 32 == w.numel()
-    return W1, hidden, Wo, bo
+    return W1, hidden, Wo, bo, dx
 
 
 def _silu(a):
@@ -71,9 +78,9 @@ def _silu(a):
 def emulate(plan, wpack, etab, x_in, cond=None, probe=None, noise=None, mode=0,
             in_shift=None, in_scale=None, out_scale=None, out_shift=None):
     """Returns (x_out [B,D], dlogp [B]) in float64."""
-    D, C, NH, H, dregs, cregs = plan[0], plan[1], plan[2], plan[3], plan[4], plan[5]
-    W1, hidden, Wo, bo = decode_wpack(plan, wpack)
-    W1x, W1c = W1[:, :D], W1[:, 2 * dregs:2 * dregs + C]
+    D, C, NH, H = plan[0], plan[1], plan[2], plan[3]
+    W1, hidden, Wo, bo, dx = decode_wpack(plan, wpack)
+    W1x, W1c = W1[:, :D], W1[:, dx:dx + C]
     etab64 = etab.double()
     ints = etab.contiguous().view(torch.int32)
     x = x_in.double()

@@ -230,9 +230,41 @@ def test_empty_batch_and_nan_flag():
 
 def test_unsupported_shapes_raise_on_gpu():
     from flowfusion_amd import flow as Fm
-    f = Fm.ODEFlow(64, [512] * 5).to(DEV).eval()                  # BASELINE config 4: kernel not built yet
+    f = Fm.ODEFlow(64, [1024] * 2).to(DEV).eval()                 # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
         f.sample(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
+    f = Fm.ODEFlow(64, [512] * 2).to(DEV).eval()                  # exact trace needs dim + 1 <= tile columns
+    with pytest.raises(NotImplementedError):
+        f.log_prob(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
+
+
+def test_config4_flow_64d_5x512():
+    """BASELINE config 4 shape (64-dim flow matching, MLP 5x512) on the 16x16x4 kernels: sampling
+    with RK4 and fixed-step Dormand-Prince, and the Hutchinson log-density extension."""
+    from flowfusion_amd import flow as Fm
+    torch.manual_seed(31)
+    f = Fm.ODEFlow(target_dimension=64, hidden_units=[512] * 5, target_shift=torch.randn(64),
+                   target_scale=torch.rand(64) + 0.5).eval()
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    fo, fo64 = flow_oracle(sd), flow_oracle(sd, torch.float64)
+    f = f.to(DEV)
+    B = 333
+    xT = torch.randn(B, 64)
+    opts = {"step_size": 1.0 / 20}
+    got = f.sample(xT.to(DEV), method="rk4", options=opts)
+    ref = fo64.sample(xT.double(), None, "rk4", opts).float()
+    assert _state_err(got, ref) < STATE_TOL
+    assert _state_err(got, fo.sample(xT, None, "rk4", opts)) < STATE_TOL
+    got = f.sample(xT[:64].to(DEV), method="dopri5_fixed", options={"step_size": 1.0 / 8})
+    assert _state_err(got, fo64.sample(xT[:64].double(), None, "dopri5_fixed", {"step_size": 1.0 / 8}).float()) < STATE_TOL
+    # conditional variant, ragged widths, 48-dim
+    torch.manual_seed(32)
+    fc = Fm.ConditionalODEFlow(target_dimension=48, conditional_dimension=9, hidden_units=[512, 300, 512]).eval()
+    sdc = {k: v.detach().clone() for k, v in fc.state_dict().items()}
+    fc = fc.to(DEV)
+    x, c = torch.randn(70, 48), torch.randn(70, 9)
+    got = fc.sample(x.to(DEV), c.to(DEV), method="midpoint", options=opts)
+    assert _state_err(got, flow_oracle(sdc, torch.float64).sample(x.double(), c.double(), "midpoint", opts).float()) < STATE_TOL
 
 
 # ---- full-size properties (BASELINE.json config 2 / 3 shapes) -----------------------------------------------

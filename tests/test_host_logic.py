@@ -45,8 +45,14 @@ def test_plan_selection_and_errors(built_library):
     assert (p.width, p.dregs) == (128, 4)
     p = _native.make_plan(32, 8, [200, 100], MODE_STATE)       # ragged widths pad to the max
     assert (p.width, p.dregs, p.cregs) == (256, 16, 8)
+    p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)          # BASELINE config 4: 16x16x4 kernels
+    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 512, 16, 0)
+    p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)
+    assert p.tile == 32                                          # narrow nets keep the 32x32x2 tile
     with pytest.raises(NotImplementedError):
-        _native.make_plan(64, 0, [512] * 5, MODE_STATE)          # config-4 shape: not compiled yet
+        _native.make_plan(64, 0, [1024] * 2, MODE_STATE)         # wider than any compiled kernel
+    with pytest.raises(NotImplementedError):
+        _native.make_plan(64, 0, [512] * 5, MODE_EXACT)          # 65 columns do not fit one wavefront
     with pytest.raises(NotImplementedError):
         _native.make_plan(32, 0, [64], MODE_EXACT)               # 33 columns do not fit one wavefront
     # launch argument checking happens before any HIP call
@@ -225,3 +231,29 @@ def test_emulated_euler_maruyama_matches_reference(name, built_library):
                                 noise_idx=torch.arange(n))
     x, _ = _emulate_score(sm, a["x_prior"], table, MODE_STATE, a.get("cond"), noise=a["noise"])
     assert max_rel(x, a["out"], floor=a["out"].abs().max().item()) < 3e-5
+
+
+def test_emulated_tile16_packing_matches_oracle(built_library):
+    """The 16x16x4 tiling (wide / high-dimensional networks): packed weights decoded by the emulator
+    reproduce the oracle for a 64-dim flow with 512-wide (and ragged) hidden layers."""
+    torch.manual_seed(5)
+    f = F.ConditionalODEFlow(target_dimension=40, conditional_dimension=5, hidden_units=[512, 200],
+                             target_shift=torch.randn(40), target_scale=torch.rand(40) + 0.5,
+                             conditional_shift=torch.randn(5), conditional_scale=torch.rand(5) + 0.5).eval()
+    net = f._net()
+    plan = _native.plan_words(net.plan(MODE_STATE))
+    assert plan[7] == 16 and plan[3] == 512
+    fo = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()}, torch.float64)
+    xT, cond = torch.randn(6, 40), torch.randn(6, 5)
+    opts = {"step_size": 0.25}
+    table = f._table(torch.tensor([1.0, 0.0]), "rk4", opts, MODE_STATE)
+    x0, _ = E.emulate(plan, net.wpack("cpu", MODE_STATE), table, xT, cond=f._norm_cond(cond), mode=MODE_STATE,
+                      out_scale=f.target_scale, out_shift=f.target_shift)
+    torch.testing.assert_close(x0, fo.sample(xT.double(), cond.double(), "rk4", opts), rtol=1e-5, atol=1e-5)
+    # Hutchinson mode on the same tiling
+    e = torch.sign(torch.randn(6, 40))
+    table = f._table(torch.tensor([0.0, 1.0]), "euler", opts, MODE_HUTCH)
+    planh = _native.plan_words(net.plan(MODE_HUTCH))
+    xn = (xT - f.target_shift) / f.target_scale
+    xTT, logj = E.emulate(planh, net.wpack("cpu", MODE_HUTCH), table, xn, cond=f._norm_cond(cond), probe=e, mode=MODE_HUTCH)
+    assert torch.isfinite(logj).all() and xTT.shape == xn.shape
