@@ -135,6 +135,8 @@ def main():
     # kernel-only durations: HIP events on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     net = sm._net()
+    from flowfusion_amd import _native
+    kernel_name = _native.lib().ff_kernel_name(net.plan(0).kernel_id).decode()
     table = sm._ode_table(torch.tensor([1.0, eps]), "rk4", opts, 0).to(device)
     n_evals = table.shape[0]
     t0 = time.perf_counter()
@@ -181,7 +183,7 @@ def main():
                        "sharding": f"batch x{world}, one RCCL all-gather per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "mlp_ode_h256_d8_c0_t0", "kernel_ms_avg": kernel_ms_avg,
+                         "kernel": kernel_name, "kernel_ms_avg": kernel_ms_avg,
                          "flop_per_launch": flop_per_launch,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "algorithmic_hbm_GBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9,

@@ -47,7 +47,11 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
         if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
     }
     const int need_t = mode != FF_MODE_STATE;
-    const char* force16 = getenv("FF_FORCE_TILE16");      // experiments: prefer the 16x16x4 kernels
+    // Preference among kernels that fit: narrowest width first (it dominates the FLOPs); at equal
+    // width the 16x16x4 two-waves-per-SIMD kernels (measured ~3% faster than 32x32x2 at width 256),
+    // then fewer first-layer k-steps.  FF_TILE=32|16 pins the tile (experiments).
+    const char* pin = getenv("FF_TILE");
+    const int pin_tile = pin ? atoi(pin) : 0;
     int best = -1;
     for (int i = 0; i < ff::g_n_kernels; ++i) {
         const ff::KernelEntry& k = ff::g_kernels[i];
@@ -55,13 +59,12 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
         const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
         if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t) continue;
         if (mode == FF_MODE_EXACT && dim + 1 > k.tile) continue;
+        if (pin_tile && k.tile != pin_tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
-        // cheapest first: width dominates the FLOPs; then the wider tile (fewer weight bytes per
-        // sample); then the first-layer k-steps
-        const bool pref_tile = force16 ? (k.tile < b.tile) : (k.tile > b.tile);
-        if (k.H < b.H || (k.H == b.H && (pref_tile || (k.tile == b.tile && k.dregs + k.cregs < b.dregs + b.cregs))))
-            best = i;
+        const int kc = k.dregs * (64 / k.tile) + k.cregs * (64 / k.tile);     // first-layer features covered
+        const int bc = b.dregs * (64 / b.tile) + b.cregs * (64 / b.tile);
+        if (k.H < b.H || (k.H == b.H && (k.tile < b.tile || (k.tile == b.tile && kc < bc)))) best = i;
     }
     if (best < 0) return FF_ERR_UNSUPPORTED;
     memset(plan, 0, sizeof(*plan));

@@ -22,8 +22,8 @@
 // stream in the exact order the kernel consumes them (layer 1, hidden layers, output layer), which
 // lets the kernel prefetch with one uniform sliding window across layer and evaluation
 // boundaries.  Within a layer of G groups and NOB logical blocks the order is
-//   phase A (groups 0 .. G-5): group-major  -- all NOB accumulators advance together;
-//   phase B (last min(G,4) groups): block-major -- accumulator ob completes after its last
+//   phase A: group-major  -- all NOB accumulators advance together;
+//   phase B (the groups of the last logical k-block, at most RB/4): block-major -- accumulator ob completes after its last
 //           chunk, so its activation can run behind the MFMAs of block ob+1.
 // Each layer's chunk count is padded to a multiple of kChunkPad (zero chunks, loaded but unused)
 // so the prefetch ring position is a compile-time constant everywhere.
@@ -74,12 +74,15 @@ struct LayerGeom {
     int CPAD;   // padded chunk count
 };
 
-FF_HD constexpr LayerGeom layer_geom(int KR, int NOB)
+// `gb_max` = operand-register groups of ONE logical block (RB / 4): phase B must not reach back
+// into the block before the last one, because that block's activation is written in place (over
+// the operands it supersedes) while phase B is still running.
+FF_HD constexpr LayerGeom layer_geom(int KR, int NOB, int gb_max)
 {
     LayerGeom g{};
     g.G = KR / 4;
     g.NOB = NOB;
-    g.GB = g.G < 4 ? g.G : 4;
+    g.GB = g.G < gb_max ? g.G : gb_max;
     g.GA = g.G - g.GB;
     g.NC = g.G * NOB;
     g.CPAD = (g.NC + kChunkPad - 1) / kChunkPad * kChunkPad;
@@ -124,9 +127,9 @@ FF_HD constexpr Layout make_layout(int tile, int H, int dregs, int cregs, int n_
     Layout L{};
     L.tile = tile; L.H = H; L.NB = H / 32; L.dregs = dregs; L.cregs = cregs; L.n_hidden = n_hidden;
     L.nob_out = blocks_for_regs(tile, dregs);
-    L.g1 = layer_geom(dregs + cregs, L.NB);
-    L.gh = layer_geom(H / tile_nq(tile), L.NB);
-    L.go = layer_geom(H / tile_nq(tile), L.nob_out);
+    L.g1 = layer_geom(dregs + cregs, L.NB, tile_rb(tile) / 4);
+    L.gh = layer_geom(H / tile_nq(tile), L.NB, tile_rb(tile) / 4);
+    L.go = layer_geom(H / tile_nq(tile), L.nob_out, tile_rb(tile) / 4);
     L.chunks_l1 = L.g1.CPAD;
     L.chunks_hid = L.gh.CPAD;
     L.chunks_out = L.go.CPAD;

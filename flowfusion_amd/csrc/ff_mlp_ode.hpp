@@ -192,7 +192,7 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
                                           LastFn&& last, DbgFn&& dbg)
 {
     typedef Tile<TILE> T;
-    constexpr LayerGeom L = layer_geom(KR, NOB);
+    constexpr LayerGeom L = layer_geom(KR, NOB, T::RB / 4);
     constexpr int CB = 1024 * T::PHYS;              // bytes per chunk
     BlockAcc<TILE> acc[NOB];
     dbg();
@@ -240,9 +240,9 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
     });
 }
 
-template <int KR, int NOB>
+template <int TILE, int KR, int NOB>
 struct GeomTag {
-    static constexpr LayerGeom value = layer_geom(KR, NOB);
+    static constexpr LayerGeom value = layer_geom(KR, NOB, Tile<TILE>::RB / 4);
 };
 
 // Activation schedule.  A logical block has GPB = RB/4 groups of 4 registers and spans
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         };
         // ---- layer 1: [x | cond] -> H, bias c1_e ---------------------------------------
         {
-            using G1 = GeomTag<K1, NB>;
+            using G1 = GeomTag<TILE, K1, NB>;
             run_layer<TILE, RING, K1, NB, false>(
                 ring, ws, lane16, 0, y,
                 [&](auto ob) {
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         }
         // ---- hidden -> hidden ------------------------------------------------------------
         for (int l = 0; l < args.n_hidden - 1; ++l) {
-            using GH = GeomTag<KH, NB>;
+            using GH = GeomTag<TILE, KH, NB>;
             const int sbyte = L.chunk_off_hid(l) * CB;
             const int bbyte = (int)(L.bias_off_hid(l) * 4);
             run_layer<TILE, RING, KH, NB, false>(
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             [&](auto mm, const BlockAcc<TILE> (&acc)[NOB_OUT]) {
                 prev_slot(mm);
                 if constexpr (NOB_OUT > 1) {          // finished output blocks: plain bias add
-                    constexpr LayerGeom GO = layer_geom(KH, NOB_OUT);
+                    constexpr LayerGeom GO = layer_geom(KH, NOB_OUT, RB / 4);
                     constexpr int M = decltype(mm)::value;
                     constexpr int id = act_group_at(GO, T::PHYS, GPB, M, 0);
                     if constexpr (id >= 0) {

@@ -15,9 +15,9 @@ def feat_of_reg(tile, r, q):
     return 32 * (r >> 3) + 16 * ((r & 7) >> 2) + 4 * q + (r & 3)
 
 
-def _geom(KR, NOB):
+def _geom(KR, NOB, gb_max):
     G = KR // 4
-    GB = min(G, 4)
+    GB = min(G, gb_max)
     GA = G - GB
     NC = G * NOB
     return dict(G=G, NOB=NOB, GB=GB, GA=GA, NC=NC, CPAD=(NC + 15) // 16 * 16)
@@ -40,7 +40,7 @@ def decode_wpack(plan, wpack):
     nob_out = (dregs + RB - 1) // RB
     CF = 256 * PHYS
     w = wpack.double()
-    g1, gh, go = _geom(dregs + cregs, NB), _geom(H // NQ, NB), _geom(H // NQ, nob_out)
+    g1, gh, go = _geom(dregs + cregs, NB, RB // 4), _geom(H // NQ, NB, RB // 4), _geom(H // NQ, nob_out, RB // 4)
     stream = g1["CPAD"] + (NH - 1) * gh["CPAD"] + go["CPAD"]
     dx, dc = dregs * NQ, cregs * NQ
 

@@ -7,9 +7,12 @@ hence through the C ABI of libflowfusion_amd.so, against
   * size-independent properties at BASELINE.json's full batch (2^20): batch-shape invariance,
     run-to-run determinism, ODE reversibility (sample then integrate back), probe sign symmetry.
 
-Tolerances (fp32 path): states within 1e-4 of the largest reference magnitude (the networks are
-random-init, so trajectories grow to O(10^2..10^3)); log-densities within 1e-4 relative -- the bar
-BASELINE.json's north_star states ("matching reference log_prob to 1e-4 rel").
+Tolerances (fp32 path): BASELINE.json's north_star asks for log_prob within 1e-4 relative.  The
+kernels do exact fp32 arithmetic (fp32 MFMA = fma chain), so they sit at fp32 rounding noise of
+the oracle (1e-6..1e-5 after hundreds of sequential network evaluations); the tests hold them to
+2e-5 -- states relative to the largest reference magnitude (the networks are random-init, so
+trajectories grow to O(10^2..10^3)), log-densities relative with an absolute floor of 1 -- which is
+tight enough to expose a single wrong operand register in one layer.
 """
 import pytest
 import torch
@@ -18,8 +21,8 @@ from tests._util import (flow_model, flow_oracle, golden_names, load_golden, max
 
 pytestmark = pytest.mark.gpu
 
-STATE_TOL = 1e-4       # relative to max |reference state|
-LOGP_TOL = 1e-4        # relative (north_star)
+STATE_TOL = 2e-5       # relative to max |reference state|
+LOGP_TOL = 2e-5        # relative, floor 1 (north_star's bar is 1e-4)
 DEV = "cuda"
 
 

@@ -39,22 +39,22 @@ def test_library_exports_every_declared_symbol(built_library):
 
 
 def test_plan_selection_and_errors(built_library):
-    p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)
-    assert (p.width, p.dregs, p.cregs) == (256, 8, 0)
-    p = _native.make_plan(2, 0, [128] * 3, MODE_HUTCH)
-    assert (p.width, p.dregs) == (128, 4)
-    p = _native.make_plan(32, 8, [200, 100], MODE_STATE)       # ragged widths pad to the max
-    assert (p.width, p.dregs, p.cregs) == (256, 16, 8)
-    p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)          # BASELINE config 4: 16x16x4 kernels
+    p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)          # bench shape: 16x16x4, two waves per SIMD
+    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 256, 4, 0)
+    p = _native.make_plan(2, 0, [128] * 3, MODE_HUTCH)            # narrower nets: 32x32x2 kernels
+    assert (p.tile, p.width, p.dregs) == (32, 128, 4)
+    p = _native.make_plan(32, 8, [200, 100], MODE_STATE)          # ragged widths pad to the max
+    assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
+    p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
     assert (p.tile, p.width, p.dregs, p.cregs) == (16, 512, 16, 0)
-    p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)
-    assert p.tile == 32                                          # narrow nets keep the 32x32x2 tile
+    p = _native.make_plan(20, 0, [256] * 2, MODE_EXACT)           # 21 columns need the 32-wide tile
+    assert p.tile == 32
     with pytest.raises(NotImplementedError):
-        _native.make_plan(64, 0, [1024] * 2, MODE_STATE)         # wider than any compiled kernel
+        _native.make_plan(64, 0, [1024] * 2, MODE_STATE)          # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
-        _native.make_plan(64, 0, [512] * 5, MODE_EXACT)          # 65 columns do not fit one wavefront
+        _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # 65 columns do not fit one wavefront
     with pytest.raises(NotImplementedError):
-        _native.make_plan(32, 0, [64], MODE_EXACT)               # 33 columns do not fit one wavefront
+        _native.make_plan(32, 0, [64], MODE_EXACT)                # 33 columns do not fit one wavefront
     # launch argument checking happens before any HIP call
     bad = _native.OdeArgs()
     rc = built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(bad), None)
