@@ -58,6 +58,8 @@ class OdeArgs(ctypes.Structure):
         ("noise_stride", ctypes.c_int64),
         ("n_evals", ctypes.c_int32),
         ("mode", ctypes.c_int32),
+        ("tangent_first", ctypes.c_int32),
+        ("tangent_count", ctypes.c_int32),
     ]
 
 
@@ -116,7 +118,7 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int) -> PlanStru
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}: "
             "compiled shapes cover dim<=32 / cond_dim<=16 / hidden width<=256 (32x32x2 kernels) and "
-            "dim<=64 / cond_dim<=16 / width<=512 (16x16x4 kernels); exact-trace mode needs dim+1 <= tile")
+            "dim<=64 / cond_dim<=16 / width<=512 (16x16x4 kernels)")
     if rc != FF_OK:
         raise _err(rc, "ff_mlp_plan")
     return p
@@ -166,7 +168,8 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
             noise: Optional[torch.Tensor], wpack: torch.Tensor, etab: torch.Tensor,
             in_shift: Optional[torch.Tensor], in_scale: Optional[torch.Tensor],
             out_scale: Optional[torch.Tensor], out_shift: Optional[torch.Tensor],
-            plan: List[int], mode: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+            plan: List[int], mode: int, tangent_first: int = 0, tangent_count: int = 0
+            ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Fused integration on the GPU: returns (final state [B,D], integrated divergence [B], status[1])."""
     if not x.is_cuda:
         raise RuntimeError("flowfusion_amd::mlp_ode needs tensors on the GPU (there is no CPU path)")
@@ -198,6 +201,8 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
     a.noise_stride = B * D
     a.n_evals = etab.shape[0]
     a.mode = mode
+    a.tangent_first = tangent_first
+    a.tangent_count = tangent_count
     if cond is not None and tuple(cond.shape) != (B, p.cond_dim):
         raise RuntimeError(f"cond has shape {tuple(cond.shape)}, expected {(B, p.cond_dim)}")
     if probe is not None and tuple(probe.shape) != (B, D):
@@ -213,7 +218,8 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
 
 
 @mlp_ode.register_fake
-def _(x, cond, probe, noise, wpack, etab, in_shift, in_scale, out_scale, out_shift, plan, mode):
+def _(x, cond, probe, noise, wpack, etab, in_shift, in_scale, out_scale, out_shift, plan, mode,
+      tangent_first=0, tangent_count=0):
     B = x.shape[0]
     return (torch.empty_like(x), x.new_empty(B if mode != MODE_STATE else 0),
             torch.empty(1, dtype=torch.int32, device=x.device))

@@ -24,12 +24,13 @@ extern "C" const char* ff_kernel_name(int id)
 
 extern "C" int ff_last_hip_error(void) { return t_last_hip_error; }
 
-static int tangents_of_mode(int mode, int dim, int* n_tangent, int* unit)
+// tangent columns per sample for a mode; `tile` bounds how many unit tangents one launch can carry
+static int tangents_of_mode(int mode, int dim, int tile, int* n_tangent, int* unit)
 {
     switch (mode) {
     case FF_MODE_STATE: *n_tangent = 0; *unit = 0; return 0;
     case FF_MODE_HUTCH: *n_tangent = 1; *unit = 0; return 0;
-    case FF_MODE_EXACT: *n_tangent = dim; *unit = 1; return (dim + 1 <= 32) ? 0 : FF_ERR_UNSUPPORTED;
+    case FF_MODE_EXACT: *n_tangent = dim < tile - 1 ? dim : tile - 1; *unit = 1; return 0;
     default: return FF_ERR_BADARG;
     }
 }
@@ -38,9 +39,7 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
                            ff_mlp_plan_t* plan)
 {
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
-    int nt, unit;
-    int rc = tangents_of_mode(mode, dim, &nt, &unit);
-    if (rc) return rc;
+    if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     int wmax = 0;
     for (int i = 0; i < n_hidden; ++i) {
         if (hidden_widths[i] < 1) return FF_ERR_BADARG;
@@ -58,7 +57,6 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
         const int need_d = ff::regs_for(k.tile, dim);
         const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
         if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t) continue;
-        if (mode == FF_MODE_EXACT && dim + 1 > k.tile) continue;
         if (pin_tile && k.tile != pin_tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
@@ -165,7 +163,7 @@ extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
 {
     if (!plan_ok(plan)) return FF_ERR_BADARG;
     int nt, unit;
-    int rc = tangents_of_mode(mode, plan->dim, &nt, &unit);
+    int rc = tangents_of_mode(mode, plan->dim, plan->tile, &nt, &unit);
     if (rc) return rc;
     return 4 * (plan->tile / (1 + nt));
 }
@@ -177,8 +175,15 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if (plan->cond_dim > 0 && !a->cond) return FF_ERR_BADARG;
     const ff::KernelEntry& k = ff::g_kernels[plan->kernel_id];
     int nt, unit;
-    int rc = tangents_of_mode(a->mode, plan->dim, &nt, &unit);
+    int rc = tangents_of_mode(a->mode, plan->dim, plan->tile, &nt, &unit);
     if (rc) return rc;
+    int tfirst = 0;
+    if (a->mode == FF_MODE_EXACT) {
+        tfirst = a->tangent_first;
+        if (a->tangent_count > 0) nt = a->tangent_count;
+        else if (plan->dim > nt) return FF_ERR_BADARG;      // must be split by the caller
+        if (tfirst < 0 || tfirst + nt > plan->dim || nt + 1 > plan->tile) return FF_ERR_BADARG;
+    }
     if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
     if (a->mode == FF_MODE_HUTCH && !a->probe) return FF_ERR_BADARG;
     if (a->mode != FF_MODE_STATE && !a->dlogp_out) return FF_ERR_BADARG;
@@ -191,14 +196,13 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
     ka.status = a->status; ka.batch = a->batch; ka.noise_stride = a->noise_stride;
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
-    ka.n_tangent = nt; ka.unit_tangents = unit;
+    ka.n_tangent = nt; ka.unit_tangents = unit; ka.tangent_first = tfirst;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     if ((size_t)a->n_evals * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     ka.wpack_floats = (int)L.total_floats;
 
-    if (a->mode == FF_MODE_EXACT && plan->dim + 1 > plan->tile) return FF_ERR_UNSUPPORTED;
     const long long spw = 4ll * (plan->tile / (1 + nt));
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;

@@ -28,6 +28,7 @@ struct KernelArgs {
     int cond_dim;
     int n_tangent;       // T: tangent columns per sample (0 in FF_MODE_STATE)
     int unit_tangents;   // 1: tangents are unit vectors (exact trace); 0: tangent = probe[sample]
+    int tangent_first;   // unit tangents cover dimensions [tangent_first, tangent_first + n_tangent)
     int etab_stride;     // floats per evaluation row = FF_ROW_HDR + H
     int wpack_floats;    // size of wpack (bounds of the buffer resource)
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product

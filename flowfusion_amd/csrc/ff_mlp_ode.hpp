@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 if (args.in_shift) v = v - args.in_shift[d];
                 if (args.in_scale) v = v / args.in_scale[d];
             } else if (args.unit_tangents) {
-                v = (d == role - 1) ? 1.0f : 0.0f;
+                v = (d == args.tangent_first + role - 1) ? 1.0f : 0.0f;
             } else {
                 v = args.probe[sample * D + d];
             }

@@ -89,10 +89,19 @@ class FusedNet:
                 raise ValueError(f"conditional must be [batch, {self.cond_dim}], got {tuple(cond.shape)}")
         else:
             cond = None
-        return torch.ops.flowfusion_amd.mlp_ode(
-            f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
-            f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift),
-            _native.plan_words(plan), mode)
+        args = (f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
+                f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift), _native.plan_words(plan), mode)
+        if mode != MODE_EXACT or self.dim + 1 <= plan.tile:
+            return torch.ops.flowfusion_amd.mlp_ode(*args)
+        # exact trace over more dimensions than one wavefront carries tangents for: the trace is a
+        # sum over dimensions, so integrate it in passes of (tile - 1) unit tangents and add up
+        per = plan.tile - 1
+        total = None
+        for first in range(0, self.dim, per):
+            y, dl, st = torch.ops.flowfusion_amd.mlp_ode(*args, first, min(per, self.dim - first))
+            total = dl if total is None else total + dl
+            status = st if first == 0 else (status | st)
+        return y, total, status
 
     # -- first layer pieces used by the table builders ---------------------------------------
     def first_layer_cpu(self):

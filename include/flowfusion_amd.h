@@ -54,9 +54,9 @@ extern "C" {
 #define FF_MODE_STATE      0    /* integrate the state only (`tile` samples per wavefront) */
 #define FF_MODE_HUTCH      1    /* state + Hutchinson divergence e^T J e in forward mode
                                    (16 samples + 16 tangent columns per wavefront)         */
-#define FF_MODE_EXACT      2    /* state + exact divergence tr J: `dim` unit tangents per
-                                   sample (reference default: diffusion.py:483-503,
-                                   flow.py:158-161)                                        */
+#define FF_MODE_EXACT      2    /* state + exact divergence tr J by unit tangents (reference
+                                   default: diffusion.py:483-503, flow.py:158-161); see
+                                   ff_ode_args.tangent_first/count                          */
 
 /* evaluation-row flag bits (word 3 of the row header) */
 #define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */
@@ -96,6 +96,11 @@ typedef struct ff_ode_args {
     int64_t      noise_stride; /* floats between consecutive noise slabs (>= batch*dim)    */
     int32_t      n_evals;    /* rows in etab                                               */
     int32_t      mode;       /* FF_MODE_*                                                  */
+    int32_t      tangent_first;  /* FF_MODE_EXACT: this launch carries the unit tangents of   */
+    int32_t      tangent_count;  /* dimensions [first, first+count); count 0 = all `dim`.  A
+                                    trace over more dimensions than fit one wavefront
+                                    (count + 1 <= plan.tile) is the sum of dlogp_out over
+                                    several launches, each of which also returns x_out.     */
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

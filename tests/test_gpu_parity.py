@@ -236,9 +236,25 @@ def test_unsupported_shapes_raise_on_gpu():
     f = Fm.ODEFlow(64, [1024] * 2).to(DEV).eval()                 # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
         f.sample(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
-    f = Fm.ODEFlow(64, [512] * 2).to(DEV).eval()                  # exact trace needs dim + 1 <= tile columns
-    with pytest.raises(NotImplementedError):
-        f.log_prob(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
+
+
+def test_exact_trace_in_several_passes():
+    """A 64-dim flow's exact divergence does not fit one wavefront (65 columns): the trace is
+    integrated in passes of tile-1 unit tangents and summed; same for a 20-dim score model."""
+    from flowfusion_amd import flow as Fm
+    torch.manual_seed(41)
+    f = Fm.ODEFlow(64, [512, 512], target_shift=torch.randn(64), target_scale=torch.rand(64) + 0.5).eval()
+    fo64 = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()}, torch.float64)
+    f = f.to(DEV)
+    x = torch.randn(9, 64) * f.target_scale.cpu() + f.target_shift.cpu()
+    opts = {"step_size": 0.125}
+    lp = f.log_prob(x.to(DEV), method="rk4", options=opts)
+    assert _logp_err(lp, fo64.log_prob(x.double(), None, "rk4", opts).float()) < LOGP_TOL
+    sm, _, so64 = _seeded_score_model(20, 0, [256, 256], "VESDE", False, 42)
+    x0 = torch.randn(11, 20)
+    o2 = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
+    lp = sm.log_prob(x0.to(DEV), method="midpoint", options=o2)
+    assert _logp_err(lp, so64.log_prob(x0.double(), None, "midpoint", o2, "exact").float()) < LOGP_TOL
 
 
 def test_config4_flow_64d_5x512():

@@ -47,14 +47,12 @@ def test_plan_selection_and_errors(built_library):
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
     p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
     assert (p.tile, p.width, p.dregs, p.cregs) == (16, 512, 16, 0)
-    p = _native.make_plan(20, 0, [256] * 2, MODE_EXACT)           # 21 columns need the 32-wide tile
-    assert p.tile == 32
+    p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
+    assert p.tile == 16 and _native.samples_per_workgroup(p, MODE_EXACT) == 4
     with pytest.raises(NotImplementedError):
         _native.make_plan(64, 0, [1024] * 2, MODE_STATE)          # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
-        _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # 65 columns do not fit one wavefront
-    with pytest.raises(NotImplementedError):
-        _native.make_plan(32, 0, [64], MODE_EXACT)                # 33 columns do not fit one wavefront
+        _native.make_plan(80, 0, [64], MODE_STATE)                # more dimensions than any compiled kernel
     # launch argument checking happens before any HIP call
     bad = _native.OdeArgs()
     rc = built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(bad), None)
