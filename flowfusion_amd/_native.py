@@ -60,6 +60,13 @@ class OdeArgs(ctypes.Structure):
         ("mode", ctypes.c_int32),
         ("tangent_first", ctypes.c_int32),
         ("tangent_count", ctypes.c_int32),
+        ("k1_in", ctypes.c_void_p),
+        ("kl1_in", ctypes.c_void_p),
+        ("dlogp_in", ctypes.c_void_p),
+        ("aux_out", ctypes.c_void_p * 4),
+        ("aux_lp_out", ctypes.c_void_p * 4),
+        ("n_aux", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -223,3 +230,59 @@ def _(x, cond, probe, noise, wpack, etab, in_shift, in_scale, out_scale, out_shi
     B = x.shape[0]
     return (torch.empty_like(x), x.new_empty(B if mode != MODE_STATE else 0),
             torch.empty(1, dtype=torch.int32, device=x.device))
+
+
+@torch.library.custom_op("flowfusion_amd::mlp_ode_step", mutates_args=())
+def mlp_ode_step(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch.Tensor],
+                 k1: Optional[torch.Tensor], kl1: Optional[torch.Tensor], dlogp0: Optional[torch.Tensor],
+                 wpack: torch.Tensor, etab: torch.Tensor, plan: List[int], mode: int, n_aux: int,
+                 tangent_first: int = 0, tangent_count: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One attempt of an embedded Runge-Kutta step (adaptive solvers): the evaluation rows of `etab`
+    fill the stage slots (slot 0 preloaded from `k1`/`kl1`), and `n_aux` linear combinations of the
+    slots, described by the two trailing rows of `etab`, are returned: (aux [n_aux, B, D],
+    aux_lp [n_aux, B])."""
+    if not x.is_cuda:
+        raise RuntimeError("flowfusion_amd::mlp_ode_step needs tensors on the GPU (there is no CPU path)")
+    dev = x.device
+    p = _plan_from_words(plan)
+    B, D = x.shape
+    aux = torch.empty(n_aux, B, D, dtype=torch.float32, device=dev)
+    aux_lp = torch.zeros(n_aux, B if mode != MODE_STATE else 0, dtype=torch.float32, device=dev)
+    if B == 0:
+        return aux, aux_lp
+    scratch = torch.empty_like(x)
+    dl = torch.empty(B if mode != MODE_STATE else 0, dtype=torch.float32, device=dev)
+    a = OdeArgs()
+    a.x_in = _chk(x, "x", dev)
+    a.x_out = scratch.data_ptr()
+    a.cond = _chk(cond, "cond", dev)
+    a.probe = _chk(probe, "probe", dev)
+    a.dlogp_out = dl.data_ptr() if mode != MODE_STATE else 0
+    a.wpack = _chk(wpack, "wpack", dev)
+    a.etab = _chk(etab, "etab", dev)
+    a.batch = B
+    a.n_evals = etab.shape[0] - 2
+    a.mode = mode
+    a.tangent_first = tangent_first
+    a.tangent_count = tangent_count
+    a.k1_in = _chk(k1, "k1", dev)
+    a.kl1_in = _chk(kl1, "kl1", dev)
+    a.dlogp_in = _chk(dlogp0, "dlogp0", dev)
+    for j in range(n_aux):
+        a.aux_out[j] = aux[j].data_ptr()
+        a.aux_lp_out[j] = aux_lp[j].data_ptr() if mode != MODE_STATE else 0
+    a.n_aux = n_aux
+    if etab.shape[1] != 32 + p.width or a.n_evals < 0:
+        raise RuntimeError("evaluation table does not match the plan")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_ode_launch")
+    return aux, aux_lp
+
+
+@mlp_ode_step.register_fake
+def _(x, cond, probe, k1, kl1, dlogp0, wpack, etab, plan, mode, n_aux, tangent_first=0, tangent_count=0):
+    B = x.shape[0]
+    return (x.new_empty(n_aux, B, x.shape[1]), x.new_empty(n_aux, B if mode != MODE_STATE else 0))

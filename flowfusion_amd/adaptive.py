@@ -1,0 +1,224 @@
+"""Adaptive Dormand-Prince 5(4) on top of the fused kernel -- the reference's *default* solver.
+
+Every ODE solve in the reference defaults to ``method="dopri5"`` (diffusion.py:572, 649, 763;
+flow.py:313 and the argument-less ``odeint`` call in ``sample``, flow.py:299-303), i.e.
+torchdiffeq's adaptive Dormand-Prince with one step size for the whole batch: the error norm is
+taken over the entire state (for a tuple state: the maximum of the per-component RMS norms), so
+every sample walks the same time grid.  That global decision is kept on the host (a few scalar
+reductions per attempted step); everything per sample runs in the fused kernel, one launch per
+attempted step: six network evaluations (stages 2..7, the first one is the FSAL derivative handed
+back in), after which the new state, the last stage, the dense-output midpoint and the error
+estimate leave the chip as linear combinations of the stage slots (ff_ode_args.aux_*).
+
+torchdiffeq (>=0.2.5,<0.3.0) is not available offline; this file restates its published algorithm
+(rk_common.py: ``_select_initial_step``, ``_runge_kutta_step``, ``_compute_error_ratio``,
+``_optimal_step_size``, 4th-order dense output ``_interp_fit`` / ``_interp_evaluate``, min/max step
+handling) including where it computes in the state's fp32 and where in float64 time.  Parity with
+the real package is unpinned; the CPU oracle carries an independent restatement that
+the GPU tests compare against.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+
+# Dormand-Prince 5(4) tableau as torchdiffeq writes it (dopri5.py)
+ALPHA = (1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
+BETA = (
+    (1 / 5,),
+    (3 / 40, 9 / 40),
+    (44 / 45, -56 / 15, 32 / 9),
+    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+    (35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84),
+)
+C_SOL = (35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0)
+C_ERROR = (
+    35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+    -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0,
+)
+C_MID = (
+    6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+    187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2,
+)
+ORDER = 5
+SAFETY, IFACTOR, DFACTOR = 0.9, 10.0, 0.2
+
+
+def _f32(v) -> torch.Tensor:
+    return torch.as_tensor(v, dtype=torch.float32)
+
+
+def _rms(t: torch.Tensor) -> torch.Tensor:
+    return t.abs().pow(2).mean().sqrt()
+
+
+def _mixed_norm(parts) -> float:
+    """max over the components of the tuple state of their RMS norms (torchdiffeq `_mixed_norm`)."""
+    return max(float(_rms(p)) for p in parts if p is not None and p.numel() > 0)
+
+
+# A step function runs ONE kernel launch:
+#   step(y, k1, lp0, kl1, t_rows [n] fp32 real times, cin [n,8], slots [n], tail_coef [4,8], use_y bits, n_aux)
+#     -> (aux [n_aux,B,D], aux_lp [n_aux,B] or None)
+StepFn = Callable[..., Tuple[torch.Tensor, Optional[torch.Tensor]]]
+
+
+def _onehot(i):
+    v = torch.zeros(8)
+    v[i] = 1.0
+    return v
+
+
+class Dopri5:
+    """Batch-global adaptive Dormand-Prince over an increasing solver-time span [t0, t1]."""
+
+    def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None):
+        opts = dict(options or {})
+        self.step = step
+        self.has_lp = has_lp
+        self.rtol = float(rtol)
+        self.atol = float(atol)
+        self.min_step = float(opts.pop("min_step", 0.0))
+        self.max_step = float(opts.pop("max_step", float("inf")))
+        self.first_step = opts.pop("first_step", None)
+        self.max_num_steps = int(opts.pop("max_num_steps", 2 ** 31 - 1))
+        for k in ("step_t", "jump_t", "norm", "dtype"):
+            if opts.get(k) is not None:
+                raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
+        self.n_attempts = 0
+        self.n_accepted = 0
+
+    # -- single launches ----------------------------------------------------------------------
+    def _deriv(self, t, y, lp, k1=None, kl1=None, h=None):
+        """f(t, y) if k1 is None, else f(t, y + h*k1) -- one evaluation row, slot 0 or 1."""
+        slot = 0 if k1 is None else 1
+        cin = torch.zeros(1, 8)
+        if k1 is not None:
+            cin[0, 0] = h
+        aux, aux_lp = self.step(y, k1, lp, kl1, _f32([t]), cin, torch.tensor([slot], dtype=torch.int32),
+                                torch.stack([_onehot(slot), torch.zeros(8), torch.zeros(8), torch.zeros(8)]), 0, 1)
+        return aux[0], (aux_lp[0] if self.has_lp else None)
+
+    def _attempt(self, t0, dt, t1, y, lp, f0, fl0):
+        """Stages 2..7 of one step from (t0, y) with step dt; returns y1, lp1, f1, fl1, mids, errors."""
+        t0f, dtf, t1f = _f32(t0), _f32(dt), _f32(t1)              # time enters the stages in the state dtype
+        ts = torch.stack([t1f if a == 1.0 else t0f + a * dtf for a in ALPHA])
+        cin = torch.zeros(6, 8)
+        for i, beta in enumerate(BETA):
+            cin[i, : len(beta)] = _f32(beta) * dtf
+        tail = torch.zeros(4, 8)
+        tail[0, :7] = dtf * _f32(C_SOL)                            # y1    = y + dt * k . c_sol
+        tail[1] = _onehot(6)                                       # f1    = k[6]
+        tail[2, :7] = dtf * _f32(C_MID)                            # y_mid = y + dt * k . c_mid
+        tail[3, :7] = dtf * _f32(C_ERROR)                          # err   = dt * k . c_error
+        aux, aux_lp = self.step(y, f0, lp, fl0, ts, cin, torch.arange(1, 7, dtype=torch.int32), tail, 0b0101, 4)
+        if self.has_lp:
+            return aux, aux_lp
+        return aux, None
+
+    # -- torchdiffeq's helpers, state in fp32 on the device, time in float64 on the host ----------
+    def _select_initial_step(self, t0, y, lp, f0, fl0):
+        scale = [self.atol + p.abs() * self.rtol for p in (y, lp) if p is not None]
+        ys = [p for p in (y, lp) if p is not None]
+        fs = [p for p in (f0, fl0) if p is not None]
+        d0 = _mixed_norm([a / s for a, s in zip(ys, scale)])
+        d1 = _mixed_norm([a / s for a, s in zip(fs, scale)])
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        h0 = float(_f32(abs(h0)))
+        f1, fl1 = self._deriv(float(_f32(t0)) + h0, y, lp, k1=f0, kl1=fl0, h=h0)
+        f1s = [p for p in (f1, fl1) if p is not None]
+        d2 = abs(_mixed_norm([(a - b) / s for a, b, s in zip(f1s, fs, scale)]) / h0)
+        if d1 <= 1e-15 and d2 <= 1e-15:
+            h1 = max(1e-6, h0 * 1e-3)
+        else:
+            h1 = (0.01 / max(d1, d2)) ** (1.0 / float(ORDER))      # called with order - 1 = 4 -> 1/(4+1)
+        return min(100 * h0, abs(h1))
+
+    def _error_ratio(self, errs, y0s, y1s):
+        parts = []
+        for e, a, b in zip(errs, y0s, y1s):
+            tol = self.atol + self.rtol * torch.max(a.abs(), b.abs())
+            parts.append(e / tol)
+        return _mixed_norm(parts)
+
+    @staticmethod
+    def _optimal_step_size(last_step, error_ratio):
+        if error_ratio != error_ratio:          # NaN propagates (torch.min/max do), the next attempt raises
+            return float("nan")
+        if error_ratio == 0:
+            return last_step * IFACTOR
+        dfactor = 1.0 if error_ratio < 1 else DFACTOR
+        factor = min(IFACTOR, max(SAFETY / error_ratio ** (1.0 / ORDER), dfactor))
+        return last_step * factor
+
+    # -- driver ----------------------------------------------------------------------------------
+    def integrate(self, t0: float, t_end: float, y: torch.Tensor, lp: Optional[torch.Tensor]):
+        """Advance (y, lp) from solver time t0 to t_end > t0; returns the dense-output values there."""
+        f0, fl0 = self._deriv(t0, y, lp)
+        dt = self.first_step if self.first_step is not None else self._select_initial_step(t0, y, lp, f0, fl0)
+        dt = float(dt)
+        t_lo, t_hi = t0, t0                      # rk_state.t0, rk_state.t1
+        interp = None
+        n_steps = 0
+        while t_end > t_hi:
+            if n_steps >= self.max_num_steps:
+                raise RuntimeError(f"max_num_steps exceeded ({n_steps}>={self.max_num_steps})")
+            ta, tb = t_hi, t_hi + dt
+            if not (ta + dt > ta):      # also catches dt = NaN after a non-finite error estimate
+                raise RuntimeError(f"underflow in dt {dt}")
+            aux, aux_lp = self._attempt(ta, dt, tb, y, lp, f0, fl0)
+            self.n_attempts += 1
+            y1, f1, ymid, yerr = aux[0], aux[1], aux[2], aux[3]
+            if self.has_lp:
+                lp1, fl1, lpmid, lperr = aux_lp[0], aux_lp[1], aux_lp[2], aux_lp[3]
+                ratio = self._error_ratio([yerr, lperr], [y, lp], [y1, lp1])
+            else:
+                ratio = self._error_ratio([yerr], [y], [y1])
+            accept = ratio <= 1
+            if dt > self.max_step:
+                accept = False
+            if dt <= self.min_step:
+                accept = True
+            if accept:
+                if not bool(torch.isfinite(y1).all()):
+                    raise RuntimeError("non-finite values in state `y`")
+                self.n_accepted += 1
+                interp = (ta, tb, dt, y, y1, ymid, f0, f1,
+                          (lp, lp1, lpmid, fl0, fl1) if self.has_lp else None)
+                t_lo, t_hi = ta, tb
+                y, f0 = y1, f1
+                if self.has_lp:
+                    lp, fl0 = lp1, fl1
+            dt = self._optimal_step_size(dt, ratio)
+            if dt == dt:
+                dt = min(max(dt, self.min_step), self.max_step)
+            n_steps += 1
+        return self._interp(interp, t_end)
+
+    @staticmethod
+    def _fit_eval(y0, y1, y_mid, f0, f1, dt, x):
+        dt = _f32(dt).to(y0.device)
+        a = 2 * dt * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+        b = dt * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+        c = dt * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+        d = dt * f0
+        e = y0
+        x = _f32(x).to(y0.device)
+        total = e + x * d
+        xp = x
+        for coef in (c, b, a):
+            xp = xp * x
+            total = total + xp * coef
+        return total
+
+    def _interp(self, interp, t):
+        ta, tb, dt, y0, y1, ymid, f0, f1, lps = interp
+        x = (t - ta) / (tb - ta)
+        y = self._fit_eval(y0, y1, ymid, f0, f1, dt, x)
+        lp = None
+        if lps is not None:
+            lp0, lp1, lpmid, fl0, fl1 = lps
+            lp = self._fit_eval(lp0, lp1, lpmid, fl0, fl1, dt, x)
+        return y, lp

@@ -8,6 +8,7 @@
 #include "ff_registry.h"
 
 static_assert(FF_MAX_SLOTS == ff::kSlots, "slot count mismatch between header and kernel");
+static_assert(FF_MAX_AUX == ff::kAux, "aux count mismatch between header and kernel");
 static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
 
 static thread_local int t_last_hip_error = 0;
@@ -197,10 +198,13 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.status = a->status; ka.batch = a->batch; ka.noise_stride = a->noise_stride;
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
     ka.n_tangent = nt; ka.unit_tangents = unit; ka.tangent_first = tfirst;
+    if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
+    ka.k1_in = a->k1_in; ka.kl1_in = a->kl1_in; ka.dlogp_in = a->dlogp_in; ka.n_aux = a->n_aux;
+    for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
-    if ((size_t)a->n_evals * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
+    if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     ka.wpack_floats = (int)L.total_floats;
 
     const long long spw = 4ll * (plan->tile / (1 + nt));

@@ -4,7 +4,8 @@
 
 namespace ff {
 
-constexpr int kSlots = 6;   // == FF_MAX_SLOTS
+constexpr int kSlots = 7;   // == FF_MAX_SLOTS (Dormand-Prince 5(4) with its FSAL stage)
+constexpr int kAux = 4;     // == FF_MAX_AUX auxiliary outputs
 
 struct KernelArgs {
     const float* x_in;
@@ -31,6 +32,14 @@ struct KernelArgs {
     int tangent_first;   // unit tangents cover dimensions [tangent_first, tangent_first + n_tangent)
     int etab_stride;     // floats per evaluation row = FF_ROW_HDR + H
     int wpack_floats;    // size of wpack (bounds of the buffer resource)
+    // adaptive stepping support: preloaded first stage, and auxiliary outputs that are linear
+    // combinations of the stage slots (see ff_ode_args in include/flowfusion_amd.h)
+    const float* k1_in;
+    const float* kl1_in;
+    const float* dlogp_in;
+    float* aux_out[kAux];
+    float* aux_lp_out[kAux];
+    int n_aux;
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
 };
 

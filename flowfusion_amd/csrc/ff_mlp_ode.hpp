@@ -351,11 +351,28 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) kl[s] = 0.f;
     float lp = 0.f;
+    if (args.k1_in) {            // first stage supplied by the caller (FSAL of the previous step)
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = feat_of_reg(TILE, 4 * j + i, qd);
+                if (d < D && !is_tangent) v[i] = args.k1_in[sample * D + d];
+            }
+            ks[j * 64] = v;
+        }
+    }
+    if constexpr (TANGENTS) {
+        // the per-sample divergence of stage 0 is carried by ONE lane of the sample (first tangent
+        // column, lane group 0); all other lanes integrate their own partial sums from zero
+        if (args.kl1_in && role == 1 && qd == 0) kl[0] = args.kl1_in[sample];
+    }
 
     const Layout L = make_layout(TILE, H, DREGS, CREGS, args.n_hidden);
     constexpr int CB = 1024 * T::PHYS;               // bytes per chunk
     const Stream ws = make_stream(args.wpack, args.wpack_floats);
-    const Stream ts = make_stream(args.etab, (long long)args.n_evals * args.etab_stride);
+    const Stream ts = make_stream(args.etab, (long long)(args.n_evals + (args.n_aux > 0 ? 2 : 0)) * args.etab_stride);
     const int out_sbyte = L.chunk_off_out() * CB;
     const int out_bias_byte = (int)(L.bias_off_out() * 4);
 
@@ -561,17 +578,59 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
-    if constexpr (TANGENTS) {
-        // sum the per-lane integrals over all lane groups and over the sample's tangent columns
+    // sum of a per-lane partial over all lane groups and over the sample's tangent columns
+    auto reduce_tangents = [&](float part) {
         float tot = 0.f;
         for (int j = 1; j <= args.n_tangent; ++j) {
 #pragma unroll
             for (int g = 0; g < T::NQ; ++g) {
                 const int src = ((g << T::SHIFT) | ((col + j) & (TILE - 1))) * 4;
-                tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp)));
+                tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, part)));
             }
         }
-        if (col_live && !is_tangent && qd == 0 && args.dlogp_out) args.dlogp_out[sample] = tot;
+        return tot;
+    };
+    const bool writer = col_live && !is_tangent;
+    float lp0 = 0.f;
+    if constexpr (TANGENTS) {
+        if (args.dlogp_in) lp0 = args.dlogp_in[sample];
+        const float tot = reduce_tangents(lp);
+        if (writer && qd == 0 && args.dlogp_out) args.dlogp_out[sample] = lp0 + tot;
+    }
+    // auxiliary outputs: aux_j = use_y_j * y + sum_s coef_j[s] * k[s]  (coefficients in the two
+    // rows that follow the evaluation rows)
+    if (args.n_aux > 0) {
+        HdrPtr t0h = (HdrPtr)(args.etab + (size_t)args.n_evals * args.etab_stride);
+        HdrPtr t1h = (HdrPtr)(args.etab + (size_t)(args.n_evals + 1) * args.etab_stride);
+        const uint32_t use_y = t0h->flags;
+        static_for<kAux>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            if (j < args.n_aux) {
+                HdrPtr th = (j < 2) ? t0h : t1h;
+                float c[kSlots];
+#pragma unroll
+                for (int s = 0; s < kSlots; ++s) c[s] = (j & 1) ? th->cout[s] : th->cin[s];
+                const float uy = ((use_y >> j) & 1u) ? 1.f : 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < R4; ++q4) {
+                    f32x4 v = uy * f32x4{x[4 * q4], x[4 * q4 + 1], x[4 * q4 + 2], x[4 * q4 + 3]};
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) v += c[s] * ks[(s * R4 + q4) * 64];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int d = feat_of_reg(TILE, 4 * q4 + i, qd);
+                        if (writer && d < D && args.aux_out[j]) args.aux_out[j][sample * D + d] = v[i];
+                    }
+                }
+                if constexpr (TANGENTS) {
+                    float part = 0.f;
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) part = __builtin_fmaf(c[s], kl[s], part);
+                    const float tot = reduce_tangents(part);
+                    if (writer && qd == 0 && args.aux_lp_out[j]) args.aux_lp_out[j][sample] = uy * lp0 + tot;
+                }
+            }
+        });
     }
     bool bad = false;
     if (col_live && !is_tangent) {

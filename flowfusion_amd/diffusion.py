@@ -9,8 +9,9 @@ model trained with the reference loads with ``load_state_dict`` and samples here
 What is native (csrc/ff_mlp_ode.hpp through the C ABI in include/flowfusion_amd.h):
 ``ScoreModel.sample_ode_from_base``, ``solve_odes_forward`` / ``log_prob`` (Hutchinson probe or
 exact trace) and ``sample_sde``, for an ``MLP`` score network with SiLU activations and a
-fixed-grid ``method`` (``euler``, ``midpoint``, ``heun3``, ``rk4`` + ``options={"step_size": h}``).
-Anything else on those methods (adaptive solvers, Hutch++/XTrace, CPU tensors) raises: there is no
+fixed-grid ``method`` (``euler``, ``midpoint``, ``heun3``, ``rk4`` + ``options={"step_size": h}``) or
+the reference's default adaptive ``dopri5`` (one launch per attempted step, adaptive.py).
+Anything else on those methods (other adaptive solvers, Hutch++/XTrace, CPU tensors) raises: there is no
 eager/CPU fallback behind them.  The small pointwise members (``MLP.forward``, ``score``,
 ``ode_drift``, the SDE schedule functions) are ordinary torch code, used by training code and to
 build the per-evaluation tables on the host.  Training losses and the adjoint branches of the
@@ -26,7 +27,7 @@ import torch
 from torch import nn
 from torch.distributions import Normal
 
-from . import solvers
+from . import adaptive, solvers
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
 
 
@@ -269,6 +270,25 @@ class ScoreModel(nn.Module):
         a, b, c1, _ = self._schedule(plan.t_eval, "ode")
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
 
+    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None):
+        """odeint(self, state, t_span, method=, atol=, rtol=, options=) on the fused kernels:
+        fixed-grid methods as one launch, ``dopri5`` as one launch per attempted step."""
+        net = self._net()
+        if method == "dopri5":
+            t = t_span.detach().to("cpu", torch.float32).double()
+            sign = -1.0 if bool(t[0] > t[-1]) else 1.0
+            sched = lambda tr: self._schedule(tr, "ode")[:3]
+            step = net.make_step(sched, sign, mode, x.device, cond=cond, probe=probe)
+            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options)
+            lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
+            y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
+                                     x.detach().to(torch.float32).contiguous(), lp0)
+            self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
+            return y, lp
+        table = self._ode_table(t_span, method, options, mode)
+        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe)
+        return y, (lp if mode != MODE_STATE else None)
+
     @torch.no_grad()
     def sample_sde(self, shape, conditional=None, steps=100):
         """Euler-Maruyama sampling of the reverse SDE; returns the last *mean* state, like the
@@ -333,8 +353,7 @@ class ScoreModel(nn.Module):
         self.prob = False
         self.conditional = conditional
         t_span = torch.tensor([1.0, float(self.sde.epsilon)], dtype=torch.float32)
-        table = self._ode_table(t_span, method, options, MODE_STATE)
-        x, _, _ = net.integrate(z, table, MODE_STATE, cond=conditional)
+        x, _ = self._solve(z, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional)
         return x, []
 
     @torch.no_grad()
@@ -356,8 +375,7 @@ class ScoreModel(nn.Module):
             probe = self.e
             mode = MODE_HUTCH
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
-        table = self._ode_table(t_span, method, options, mode)
-        xT, dlogp, _ = net.integrate(x0_samples, table, mode, cond=conditional, probe=probe)
+        xT, dlogp = self._solve(x0_samples, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe)
         return xT, dlogp.view(-1, 1)
 
     @torch.no_grad()

@@ -21,7 +21,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import solvers
+from . import adaptive, solvers
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
 
 _DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
@@ -55,37 +55,59 @@ class _FlowBase(nn.Module):
             object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1))
         return self._fused
 
-    def _table(self, t_span, method, options, mode):
-        net = self._net()
-        plan = solvers.plan_ode(t_span, method, options)
-        w0, b0 = net.first_layer_cpu()
+    def _schedule(self, t):
+        """(a, b, c1) for real times t (fp32, CPU): xdot = NET([x, t, cond]) -> a = 0, b = 1,
+        c1 = w_t * t + bias of the first layer (flow.py:112-118)."""
+        w0, b0 = self._net().first_layer_cpu()
         D = self.target_dimension
-        t = plan.t_eval
         c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
-        zeros = torch.zeros_like(t)
-        return solvers.build_table(plan, zeros, torch.ones_like(t), c1, net.width(mode))
+        return torch.zeros_like(t), torch.ones_like(t), c1
+
+    def _table(self, t_span, method, options, mode):
+        plan = solvers.plan_ode(t_span, method, options)
+        a, b, c1 = self._schedule(plan.t_eval)
+        return solvers.build_table(plan, a, b, c1, self._net().width(mode))
 
     def _norm_cond(self, conditional):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
-    def _fused_sample(self, xT, conditional, method, options):
+    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, **affine):
+        net = self._net()
+        if method == "dopri5":
+            if any(v is not None for v in affine.values()):
+                raise AssertionError("affine epilogues are applied by the caller on the adaptive path")
+            t = t_span.double()
+            sign = -1.0 if bool(t[0] > t[-1]) else 1.0
+            step = net.make_step(self._schedule, sign, mode, x.device, cond=cond, probe=probe)
+            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options)
+            lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
+            y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
+                                     x.detach().to(torch.float32).contiguous(), lp0)
+            self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
+            return y, lp
+        table = self._table(t_span, method, options, mode)
+        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
+        return y, (lp if mode != MODE_STATE else None)
+
+    def _fused_sample(self, xT, conditional, method, options, atol, rtol):
         if torch.is_grad_enabled() and xT.requires_grad:
             raise NotImplementedError("gradients through the fused solve are not available; detach the input")
         method = _DEFAULT_SAMPLE_METHOD if method is None else method
         t_span = torch.tensor([1.0, 0.0], dtype=torch.float32)
-        table = self._table(t_span, method, options, MODE_STATE)
-        x, _, _ = self._net().integrate(xT, table, MODE_STATE, cond=conditional,
-                                        out_scale=self.target_scale, out_shift=self.target_shift)
+        if method == "dopri5":
+            x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional)
+            return x * self.target_scale + self.target_shift
+        x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional,
+                           out_scale=self.target_scale, out_shift=self.target_shift)
         return x
 
-    def _fused_forward(self, x, conditional, method, options, hutchinson):
+    def _fused_forward(self, x, conditional, method, options, hutchinson, atol, rtol):
         t_span = torch.tensor([0.0, 1.0], dtype=torch.float32)
         mode, probe = MODE_EXACT, None
         if hutchinson:
             mode = MODE_HUTCH
             probe = torch.sign(torch.randn(x.shape)).to(x.device)
-        table = self._table(t_span, method, options, mode)
-        xT, logj, _ = self._net().integrate(x, table, mode, cond=conditional, probe=probe)
+        xT, logj = self._solve(x, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe)
         return xT, logj.view(-1, 1)
 
 
@@ -127,19 +149,19 @@ class ODEFlow(_FlowBase):
 
     # -- fused ------------------------------------------------------------------------------------
     def sample(self, xT: torch.Tensor, gradients: bool = False, method: Optional[str] = None,
-               options: Optional[dict] = None):
+               options: Optional[dict] = None, atol: float = 1e-9, rtol: float = 1e-7):
         """Transport base samples xT (t=1) to the target (t=0), then ``* target_scale + target_shift``."""
         if gradients:
             raise NotImplementedError("sample(gradients=True) uses odeint_adjoint in the reference "
                                       "(flow.py:286-295); differentiable solves are out of scope")
-        return self._fused_sample(xT, None, method, options)
+        return self._fused_sample(xT, None, method, options, atol, rtol)
 
     def solve_ode_forward(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
                           options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
         """Integrate t: 0 -> 1 with the divergence; returns ``(xT, log_jacobian[B,1])`` (flow.py:308-384)."""
         if adjoint:
             raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
-        return self._fused_forward(x, None, method, options, hutchinson)
+        return self._fused_forward(x, None, method, options, hutchinson, atol, rtol)
 
     def log_prob(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
                  options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
@@ -198,18 +220,18 @@ class ConditionalODEFlow(_FlowBase):
 
     # -- fused ------------------------------------------------------------------------------------
     def sample(self, xT, conditional, gradients: bool = False, method: Optional[str] = None,
-               options: Optional[dict] = None):
+               options: Optional[dict] = None, atol: float = 1e-9, rtol: float = 1e-7):
         if gradients:
             raise NotImplementedError("sample(gradients=True) uses odeint_adjoint in the reference "
                                       "(flow.py:779-788); differentiable solves are out of scope")
-        return self._fused_sample(xT, self._norm_cond(conditional), method, options)
+        return self._fused_sample(xT, self._norm_cond(conditional), method, options, atol, rtol)
 
     def solve_ode_forward(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5,
                           method: str = "dopri5", options: Optional[dict] = None, adjoint: bool = False,
                           hutchinson: bool = False):
         if adjoint:
             raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
-        return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson)
+        return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson, atol, rtol)
 
     def log_prob(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
                  options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):

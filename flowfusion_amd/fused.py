@@ -103,6 +103,48 @@ class FusedNet:
             status = st if first == 0 else (status | st)
         return y, total, status
 
+    # -- adaptive stepping: one launch per attempted step (flowfusion_amd/adaptive.py) -----------
+    def make_step(self, schedule, sign: float, mode: int, device, cond=None, probe=None, launcher=None):
+        """Step function for ``adaptive.Dopri5``.  ``schedule(t_real fp32 [n]) -> (a, b, c1)`` supplies
+        the time-dependent scalars and first-layer bias; ``sign`` = -1 for a decreasing span (solved
+        in reversed time with the right-hand side negated).  ``launcher`` replaces the GPU launch in
+        the CPU tests (kernel-semantics emulator)."""
+        plan = self.plan(mode)
+        width = plan.width
+        words = _native.plan_words(plan)
+        f32 = lambda t: None if t is None else t.detach().to(device, torch.float32).contiguous()
+        cond_d = f32(cond) if self.cond_dim > 0 else None
+        probe_d = f32(probe)
+        if launcher is None:
+            wpack = self.wpack(device, mode)
+            launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count: torch.ops.flowfusion_amd.mlp_ode_step(
+                y, cond_d, probe_d, k1, kl1, lp0, wpack, etab.to(device), words, mode, n_aux, first, count)
+        per = plan.tile - 1
+        passes = [(0, 0)] if (mode != MODE_EXACT or self.dim + 1 <= plan.tile) else \
+            [(first, min(per, self.dim - first)) for first in range(0, self.dim, per)]
+
+        def step(y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux):
+            n = int(t_rows.numel())
+            a, b, c1 = schedule(sign * t_rows)
+            rows = torch.zeros(n + 2, 32 + width, dtype=torch.float32)
+            rows[:n, 0] = sign * a
+            rows[:n, 1] = sign * b
+            ints = rows.view(torch.int32)
+            ints[:n, 4] = slots
+            rows[:n, 8:16] = cin
+            rows[:n, 32:32 + c1.shape[1]] = c1
+            rows[n, 8:16], rows[n, 16:24] = tail[0], tail[1]
+            rows[n + 1, 8:16], rows[n + 1, 16:24] = tail[2], tail[3]
+            ints[n, 3] = use_y
+            aux = aux_lp = None
+            for i, (first, count) in enumerate(passes):
+                o, olp = launcher(y, k1, kl1 if i == 0 else None, lp0 if i == 0 else None, rows, n_aux, first, count)
+                aux = o if aux is None else aux
+                aux_lp = olp if aux_lp is None else aux_lp + olp
+            return aux, (aux_lp if mode != MODE_STATE else None)
+
+        return step
+
     # -- first layer pieces used by the table builders ---------------------------------------
     def first_layer_cpu(self):
         l0 = self.linears[0]

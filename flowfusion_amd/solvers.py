@@ -24,7 +24,7 @@ from typing import Callable, Optional, Sequence
 import torch
 
 ROW_HDR = 32          # words in the row header (FF_ROW_HDR)
-MAX_SLOTS = 6         # stage slots on chip (FF_MAX_SLOTS)
+MAX_SLOTS = 7         # stage slots on chip (FF_MAX_SLOTS)
 FLAG_STEP_END = 1
 FLAG_NOISE = 2
 

@@ -47,7 +47,8 @@ extern "C" {
 #define FF_ERR_UNSUPPORTED -2   /* no gfx950 kernel instantiation covers this shape        */
 #define FF_ERR_HIP         -3   /* HIP runtime refused the launch (see ff_last_hip_error)  */
 
-#define FF_MAX_SLOTS   6        /* Runge-Kutta stage slots kept on chip                    */
+#define FF_MAX_SLOTS   7        /* Runge-Kutta stage slots kept on chip (dopri5 + FSAL)    */
+#define FF_MAX_AUX     4        /* auxiliary linear-combination outputs per launch         */
 #define FF_ROW_HDR     32       /* 4-byte words in the header of one evaluation row        */
 
 /* mode flags for ff_ode_args.mode */
@@ -101,6 +102,23 @@ typedef struct ff_ode_args {
                                     trace over more dimensions than fit one wavefront
                                     (count + 1 <= plan.tile) is the sum of dlogp_out over
                                     several launches, each of which also returns x_out.     */
+    /* --- adaptive stepping support (all optional; zero / NULL when unused) ---------------------
+     * One attempt of an embedded Runge-Kutta step is one launch: the first stage k[0] is supplied
+     * by the caller (FSAL), the evaluation rows fill the other slots WITHOUT a STEP_END flag, and
+     * the results leave as linear combinations of the slots,
+     *     aux_j = use_y_j * y_in + sum_s coef_j[s] * k[s]          j < n_aux <= FF_MAX_AUX
+     * (new state, last stage, dense-output midpoint, error estimate).  Their coefficients live in
+     * two extra rows appended to etab (so etab has n_evals + 2 rows): row n_evals carries coef_0
+     * in its cin words, coef_1 in its cout words and the use_y bits in its flags word; row
+     * n_evals+1 carries coef_2 / coef_3 the same way.  With a divergence mode the same
+     * combinations of the divergence slots (and use_y_j * dlogp_in) go to aux_lp_out[j]. */
+    const float* k1_in;      /* [batch, dim]  stage slot 0 (derivative at the step start) or NULL */
+    const float* kl1_in;     /* [batch]       divergence of stage slot 0 or NULL                  */
+    const float* dlogp_in;   /* [batch]       integrated divergence at the step start or NULL     */
+    float*       aux_out[FF_MAX_AUX];     /* [batch, dim] each, or NULL                            */
+    float*       aux_lp_out[FF_MAX_AUX];  /* [batch] each, or NULL                                 */
+    int32_t      n_aux;
+    int32_t      reserved;
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

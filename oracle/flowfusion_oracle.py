@@ -205,24 +205,26 @@ class ScoreOracle:
         return x_dot.detach(), div.detach().view(x.shape[0], 1)       # :505-506
 
     # ---- solves ------------------------------------------------------------------------------------
-    def sample_ode_from_base(self, base, conditional=None, method="rk4", options=None):
+    def sample_ode_from_base(self, base, conditional=None, method="rk4", options=None, atol=1e-4, rtol=1e-4):
         """diffusion.py:566-640 (returns just the samples)."""
         z = base * self.sde.base_scale if self.sde.base_scale is not None else base     # :605-608
         times = torch.stack([torch.tensor(1.0, dtype=torch.float32), self.sde.epsilon.to(torch.float32)]).to(self.dtype)  # :611
         func = lambda t, y: self.rhs(t, y, conditional, None)
-        (traj,) = odeint_fixed(func, (z,), times, method, options)
+        (traj,) = odeint(func, (z,), times, method, options, rtol, atol)
         return traj
 
-    def solve_odes_forward(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None):
+    def solve_odes_forward(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None,
+                           atol=1e-5, rtol=1e-5):
         """diffusion.py:642-754 -> (xT, delta_logp[B,1])."""
         dlogp = torch.zeros(x0.shape[0], 1, dtype=x0.dtype)         # :724
         times = torch.stack([self.sde.epsilon.to(torch.float32), torch.tensor(1.0, dtype=torch.float32)]).to(self.dtype)  # :727
         func = lambda t, y: self.rhs(t, y, conditional, divergence, e)
-        return odeint_fixed(func, (x0, dlogp), times, method, options)
+        return odeint(func, (x0, dlogp), times, method, options, rtol, atol)
 
-    def log_prob(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None):
+    def log_prob(self, x0, conditional=None, method="rk4", options=None, divergence="hutch", e=None,
+                 atol=1e-4, rtol=1e-4):
         """diffusion.py:756-815 -> [B,1]."""
-        xT, lp = self.solve_odes_forward(x0, conditional, method, options, divergence, e)
+        xT, lp = self.solve_odes_forward(x0, conditional, method, options, divergence, e, atol, rtol)
         return lp + torch.sum(normal_log_prob(xT, self.sde.prior_scale()), dim=1, keepdim=True)   # :814
 
     def sample_sde(self, x_prior, noise: Sequence[torch.Tensor], conditional=None, steps=100):
@@ -357,6 +359,121 @@ def odeint_fixed(func: Callable, y0: Tuple[torch.Tensor, ...], t: torch.Tensor, 
 
 
 # =================================================================================================
+# adaptive Dormand-Prince 5(4)  (restatement of torchdiffeq's dopri5 -- parity unpinned, see header)
+# =================================================================================================
+_DP5_ALPHA = [1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP5_BETA = [[1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9],
+             [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+             [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+             [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]]
+_DP5_C_SOL = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0]
+_DP5_C_ERR = [35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+              -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1.0 / 60.0]
+_DP5_C_MID = [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+              187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+def _tuple_norm(parts):
+    """torchdiffeq's default norm for tuple states: max over components of the RMS norm."""
+    return max(p.abs().pow(2).mean().sqrt() for p in parts)
+
+
+def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
+    """Adaptive dopri5 from ``t[0]`` to ``t[-1]`` for a tuple state; returns the tuple at ``t[-1]``.
+
+    Follows torchdiffeq's RKAdaptiveStepsizeODESolver: float64 time, stages evaluated with the time
+    cast to the state dtype, one step size for the whole batch chosen from the mixed RMS norm of
+    err / (atol + rtol * max(|y0|, |y1|)), safety 0.9, growth <= 10, shrink >= 0.2, initial step by
+    Hairer's rule, and the value at ``t[-1]`` read off the 4th-order dense output of the last step.
+    """
+    opts = dict(options or {})
+    min_step = float(opts.get("min_step", 0.0))
+    max_step = float(opts.get("max_step", float("inf")))
+    t = t.double()
+    if bool(t[0] > t[-1]):
+        t = -t
+        base = func
+        func = lambda tt, yy: tuple(-f for f in base(-tt, yy))
+    dty = y0[0].dtype
+    comb = lambda ks, coefs, scale: tuple(
+        sum(k[j] * (coefs[i] * scale) for i, k in enumerate(ks)) for j in range(len(y0)))
+    t0 = t[0]
+    f0 = func(t0.to(dty), y0)
+    # initial step (order - 1 = 4 is what the solver passes)
+    scale = tuple(atol + a.abs() * rtol for a in y0)
+    d0 = _tuple_norm([a / s for a, s in zip(y0, scale)])
+    d1 = _tuple_norm([a / s for a, s in zip(f0, scale)])
+    h0 = torch.tensor(1e-6, dtype=dty) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    h0 = h0.abs()
+    y1 = tuple(a + h0 * b for a, b in zip(y0, f0))
+    f1 = func(t0.to(dty) + h0, y1)
+    d2 = (_tuple_norm([(a - b) / s for a, b, s in zip(f1, f0, scale)]) / h0).abs()
+    if d1 <= 1e-15 and d2 <= 1e-15:
+        h1 = torch.max(torch.tensor(1e-6, dtype=dty), h0 * 1e-3)
+    else:
+        h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    dt = torch.min(100 * h0, h1.abs()).double()
+
+    y, f = tuple(y0), f0
+    t_lo = t_hi = t0
+    last = None
+    while t[-1] > t_hi:
+        ta, tb = t_hi, t_hi + dt
+        ta32, dt32, tb32 = ta.to(dty), dt.to(dty), tb.to(dty)
+        ks = [f]
+        for alpha, beta in zip(_DP5_ALPHA, _DP5_BETA):
+            ti = tb32 if alpha == 1.0 else ta32 + alpha * dt32
+            yi = tuple(a + b for a, b in zip(y, comb(ks, beta, dt32)))
+            ks.append(func(ti, yi))
+        y1 = tuple(a + b for a, b in zip(y, comb(ks, _DP5_C_SOL, dt32)))
+        f1 = ks[-1]
+        err = comb(ks, _DP5_C_ERR, dt32)
+        tol = tuple(atol + rtol * torch.max(a.abs(), b.abs()) for a, b in zip(y, y1))
+        ratio = _tuple_norm([e / s for e, s in zip(err, tol)]).abs()
+        accept = bool(ratio <= 1)
+        if dt > max_step:
+            accept = False
+        if dt <= min_step:
+            accept = True
+        if accept:
+            ymid = tuple(a + b for a, b in zip(y, comb(ks, _DP5_C_MID, dt32)))
+            last = (ta, tb, dt32, y, y1, ymid, f, f1)
+            t_lo, t_hi = ta, tb
+            y, f = y1, f1
+        ratio = ratio.double()
+        if bool(torch.isnan(ratio)):
+            raise AssertionError("underflow in dt nan")       # what torchdiffeq's next attempt asserts
+        if ratio == 0:
+            dt = dt * 10.0
+        else:
+            dfactor = 1.0 if ratio < 1 else 0.2
+            dt = dt * min(10.0, max(0.9 / float(ratio) ** 0.2, dfactor))
+        dt = dt.clamp(min_step, max_step)
+    ta, tb, dt32, ya, yb, ymid, fa, fb = last
+    x = ((t[-1] - ta) / (tb - ta)).to(dty)
+    out = []
+    for y_0, y_1, y_m, f_0, f_1 in zip(ya, yb, ymid, fa, fb):
+        a = 2 * dt32 * (f_1 - f_0) - 8 * (y_1 + y_0) + 16 * y_m
+        b = dt32 * (5 * f_0 - 3 * f_1) + 18 * y_0 + 14 * y_1 - 32 * y_m
+        c = dt32 * (f_1 - 4 * f_0) - 11 * y_0 - 5 * y_1 + 16 * y_m
+        d = dt32 * f_0
+        total = y_0 + x * d
+        xp = x
+        for coef in (c, b, a):
+            xp = xp * x
+            total = total + xp * coef
+        out.append(total)
+    return tuple(out)
+
+
+def odeint(func, y0, t, method="rk4", options=None, rtol=1e-7, atol=1e-9):
+    """Dispatch like torchdiffeq.odeint for the methods restated here."""
+    if method == "dopri5":
+        return odeint_dopri5(func, y0, t, rtol, atol, options)
+    return odeint_fixed(func, y0, t, method, options)
+
+
+# =================================================================================================
 # flows  (flow.py)
 # =================================================================================================
 @dataclass
@@ -417,24 +534,25 @@ class FlowOracle:
                 div = div + torch.autograd.grad(dxdt[:, i].sum(), x, retain_graph=True)[0][:, i].unsqueeze(1)
         return dxdt.detach(), div.detach()
 
-    def sample(self, xT, conditional=None, method="rk4", options=None):
-        """flow.py:282-305 / :775-798: integrate t: 1 -> 0, then ``* target_scale + target_shift``."""
+    def sample(self, xT, conditional=None, method="rk4", options=None, atol=1e-9, rtol=1e-7):
+        """flow.py:282-305 / :775-798: integrate t: 1 -> 0, then ``* target_scale + target_shift``
+        (the reference passes no tolerances here, so torchdiffeq's defaults apply)."""
         times = torch.tensor([1.0, 0.0], dtype=torch.float32).to(self.dtype)
         with torch.no_grad():
             func = lambda t, y: (self.dynamics(t, y[0], conditional),)
-            (x0,) = odeint_fixed(func, (xT,), times, method, options)
+            (x0,) = odeint(func, (xT,), times, method, options, rtol, atol)
         return x0 * self.p.target_scale + self.p.target_shift
 
-    def solve_ode_forward(self, x, conditional=None, method="rk4", options=None):
+    def solve_ode_forward(self, x, conditional=None, method="rk4", options=None, atol=1e-5, rtol=1e-5):
         """flow.py:347-384 / :844-883 -> (xT, log_jacobian[B,1])."""
         logj = torch.zeros(x.shape[0], 1, dtype=x.dtype)
         times = torch.tensor([0.0, 1.0], dtype=torch.float32).to(self.dtype)
         func = lambda t, y: self.dynamics_with_jacobian(t, y[0], conditional)
-        return odeint_fixed(func, (x, logj), times, method, options)
+        return odeint(func, (x, logj), times, method, options, rtol, atol)
 
-    def log_prob(self, x, conditional=None, method="rk4", options=None):
+    def log_prob(self, x, conditional=None, method="rk4", options=None, atol=1e-5, rtol=1e-5):
         """flow.py:420-438 / :922-941 -> [B]."""
         x = (x - self.p.target_shift) / self.p.target_scale
-        xT, logj = self.solve_ode_forward(x, conditional, method, options)
+        xT, logj = self.solve_ode_forward(x, conditional, method, options, atol, rtol)
         lp = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
         return lp + logj.squeeze(1) - torch.sum(torch.log(self.p.target_scale))

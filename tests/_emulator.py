@@ -75,34 +75,18 @@ def _silu(a):
     return a * s, s + a * s * (1 - s)
 
 
-def emulate(plan, wpack, etab, x_in, cond=None, probe=None, noise=None, mode=0,
-            in_shift=None, in_scale=None, out_scale=None, out_shift=None):
-    """Returns (x_out [B,D], dlogp [B]) in float64."""
+def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp):
+    """The kernel's evaluation loop over the first n_rows rows of etab (float64)."""
     D, C, NH, H = plan[0], plan[1], plan[2], plan[3]
     W1, hidden, Wo, bo, dx = decode_wpack(plan, wpack)
     W1x, W1c = W1[:, :D], W1[:, dx:dx + C]
     etab64 = etab.double()
     ints = etab.contiguous().view(torch.int32)
-    x = x_in.double()
-    if in_shift is not None:
-        x = x - in_shift.double()
-    if in_scale is not None:
-        x = x / in_scale.double()
-    B = x.shape[0]
-    if mode == 0:
-        V = None
-    elif mode == 1:
-        V = probe.double()[:, None, :]                          # [B, T=1, D]
-    else:
-        V = torch.eye(D, dtype=torch.float64)[None].expand(B, D, D)
-    ks = torch.zeros(6, B, D, dtype=torch.float64)
-    kl = torch.zeros(6, B, dtype=torch.float64)
-    lp = torch.zeros(B, dtype=torch.float64)
     cc = cond.double() @ W1c.T if C else 0.0
-    for e in range(etab.shape[0]):
+    for e in range(n_rows):
         a, b, gn = etab64[e, 0], etab64[e, 1], etab64[e, 2]
         flags, slot, nidx = int(ints[e, 3]), int(ints[e, 4]), int(ints[e, 5])
-        cin, cout = etab64[e, 8:14], etab64[e, 16:22]
+        cin, cout = etab64[e, 8:15], etab64[e, 16:23]
         c1 = etab64[e, 32:32 + H]
         y = x + torch.einsum("s,sbd->bd", cin, ks)
         pre = y @ W1x.T + cc + c1
@@ -117,19 +101,75 @@ def emulate(plan, wpack, etab, x_in, cond=None, probe=None, noise=None, mode=0,
             if V is not None:
                 dh = dh_fac[:, None, :] * dpre
         net = (h @ Wo.T + bo)[:, :D]
-        rhs = a * y + b * net
-        ks[slot] = rhs
+        ks[slot] = a * y + b * net
         if V is not None:
             dnet = (dh @ Wo.T)[:, :, :D]                        # [B,T,D]
-            div = a * (V * V).sum((1, 2)) + b * (V * dnet).sum((1, 2))
-            kl[slot] = div
+            kl[slot] = a * (V * V).sum((1, 2)) + b * (V * dnet).sum((1, 2))
         if flags & 1:
             x = x + torch.einsum("s,sbd->bd", cout, ks)
             lp = lp + torch.einsum("s,sb->b", cout, kl)
         if flags & 2:
             x = x + gn * noise[nidx].double()
+    return x, lp
+
+
+def _tangents(plan, mode, probe, B, first=0, count=0):
+    D = plan[0]
+    if mode == 0:
+        return None
+    if mode == 1:
+        return probe.double()[:, None, :]                       # [B, T=1, D]
+    eye = torch.eye(D, dtype=torch.float64)
+    if count:
+        eye = eye[first:first + count]
+    return eye[None].expand(B, eye.shape[0], D)
+
+
+def emulate(plan, wpack, etab, x_in, cond=None, probe=None, noise=None, mode=0,
+            in_shift=None, in_scale=None, out_scale=None, out_shift=None):
+    """Returns (x_out [B,D], dlogp [B]) in float64."""
+    D = plan[0]
+    x = x_in.double()
+    if in_shift is not None:
+        x = x - in_shift.double()
+    if in_scale is not None:
+        x = x / in_scale.double()
+    B = x.shape[0]
+    ks = torch.zeros(7, B, D, dtype=torch.float64)
+    kl = torch.zeros(7, B, dtype=torch.float64)
+    x, lp = _run(plan, wpack, etab, etab.shape[0], x, cond, _tangents(plan, mode, probe, B), noise, ks, kl,
+                 torch.zeros(B, dtype=torch.float64))
     if out_scale is not None:
         x = x * out_scale.double()
     if out_shift is not None:
         x = x + out_shift.double()
     return x, lp
+
+
+def emulate_step(plan, wpack, etab, y, cond, probe, k1, kl1, lp0, mode, n_aux, first=0, count=0):
+    """ff_mlp_ode_launch with the adaptive-step extras: slot 0 preloaded, n_aux linear combinations
+    of the slots described by the two trailing rows.  Returns (aux [n_aux,B,D], aux_lp [n_aux,B]) fp32."""
+    D = plan[0]
+    x = y.double()
+    B = x.shape[0]
+    ks = torch.zeros(7, B, D, dtype=torch.float64)
+    kl = torch.zeros(7, B, dtype=torch.float64)
+    if k1 is not None:
+        ks[0] = k1.double()
+    if kl1 is not None:
+        kl[0] = kl1.double()
+    n = etab.shape[0] - 2
+    x, _ = _run(plan, wpack, etab, n, x, cond, _tangents(plan, mode, probe, B, first, count), None, ks, kl,
+                torch.zeros(B, dtype=torch.float64))
+    e64 = etab.double()
+    use_y = int(etab.contiguous().view(torch.int32)[n, 3])
+    coefs = [e64[n, 8:15], e64[n, 16:23], e64[n + 1, 8:15], e64[n + 1, 16:23]]
+    aux = torch.zeros(n_aux, B, D, dtype=torch.float64)
+    aux_lp = torch.zeros(n_aux, B if mode else 0, dtype=torch.float64)
+    l0 = lp0.double() if lp0 is not None else torch.zeros(B, dtype=torch.float64)
+    for j in range(n_aux):
+        uy = float((use_y >> j) & 1)
+        aux[j] = uy * x + torch.einsum("s,sbd->bd", coefs[j], ks)
+        if mode:
+            aux_lp[j] = uy * l0 + torch.einsum("s,sb->b", coefs[j], kl)
+    return aux.float(), aux_lp.float()

@@ -340,3 +340,55 @@ def test_full_size_log_prob_properties():
     lp = dlp[idx].view(-1, 1) + sm.sde.prior(xT[idx].shape).log_prob(xT[idx]).sum(1, keepdim=True)
     ref = so32.log_prob(x0[idx].cpu(), None, "rk4", opts, "hutch", e[idx].cpu())
     assert _logp_err(lp, ref) < LOGP_TOL
+
+
+# ---- adaptive dopri5: the reference's default method ----------------------------------------------------
+ADAPT_TOL = 2e-4       # two adaptive solves agree to about the solver tolerance (rtol = atol = 1e-5 .. 1e-4)
+
+
+def test_default_arguments_run_natively_ve():
+    """ScoreModel with a VE SDE, every solver argument left at the reference's default (dopri5,
+    atol = rtol = 1e-4, exact trace, min_step 1e-6): sample_ode_from_base and log_prob."""
+    sm, so32, so64 = _seeded_score_model(4, 0, [128, 128], "VESDE", False, 51)
+    torch.manual_seed(8)
+    base = torch.randn(300, 4)
+    x, empty = sm.sample_ode_from_base(base.to(DEV))
+    assert empty == [] and sm.last_solver_stats["accepted"] >= 3
+    ref = so32.sample_ode_from_base(base, None, "dopri5", None, 1e-4, 1e-4)
+    assert _state_err(x, ref) < ADAPT_TOL
+    x0 = torch.randn(64, 4) * 0.5
+    lp = sm.log_prob(x0.to(DEV))                              # exact trace, dopri5, options={"min_step": 1e-6}
+    ref = so32.log_prob(x0, None, "dopri5", {"min_step": 1e-6}, "exact", None, 1e-4, 1e-4)
+    assert lp.shape == (64, 1) and _logp_err(lp, ref) < ADAPT_TOL
+    sm.hutch = True
+    torch.manual_seed(5)
+    lp = sm.log_prob(x0.to(DEV), atol=1e-5, rtol=1e-5)
+    ref = so32.log_prob(x0, None, "dopri5", {"min_step": 1e-6}, "hutch", sm.e.cpu(), 1e-5, 1e-5)
+    assert _logp_err(lp, ref) < ADAPT_TOL
+
+
+def test_default_arguments_flows_and_wrappers():
+    from flowfusion_amd import flow as Fm
+    from flowfusion_amd import diffusion as Dm
+    torch.manual_seed(61)
+    f = Fm.ConditionalODEFlow(target_dimension=5, conditional_dimension=3, hidden_units=[128, 128],
+                              target_shift=torch.randn(5), target_scale=torch.rand(5) + 0.5).eval()
+    fo = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()})
+    f = f.to(DEV)
+    xT, c = torch.randn(200, 5), torch.randn(200, 3)
+    got = f.sample(xT.to(DEV), c.to(DEV))                     # reference signature: odeint defaults (rtol 1e-7, atol 1e-9)
+    assert _state_err(got, fo.sample(xT, c, "dopri5", None)) < ADAPT_TOL
+    x = xT[:40] * f.target_scale.cpu() + f.target_shift.cpu()
+    lp = f.log_prob(x.to(DEV), c[:40].to(DEV))                # dopri5, atol = rtol = 1e-5, exact divergence
+    assert lp.shape == (40,) and _logp_err(lp, fo.log_prob(x, c[:40], "dopri5", None, 1e-5, 1e-5)) < ADAPT_TOL
+    # PopulationModelDiffusion: affine wrapper, log_prob ignores self.method (reference quirk) -> dopri5
+    torch.manual_seed(62)
+    mlp = Dm.MLP(3, 0, 8, [64, 64])
+    pm = Dm.PopulationModelDiffusion(model=mlp, sde=Dm.VESDE(), shift=torch.randn(3), scale=torch.rand(3) + 0.5,
+                                     method="rk4", options={"step_size": 0.02}).to(DEV).eval()
+    z = torch.randn(50, 3, device=DEV)
+    out = pm(z)
+    ref, _ = pm.score_model.sample_ode_from_base(z, method="rk4", options={"step_size": 0.02})
+    assert torch.equal(out, ref * pm.scale + pm.shift)
+    s = pm.sample_sde((20, 3), steps=5)                       # `steps` is ignored by the reference wrapper: 100
+    assert s.shape == (20, 3) and torch.isfinite(s).all()

@@ -63,14 +63,16 @@ def test_no_cpu_fallback(built_library):
     sm = D.ScoreModel(D.MLP(4, 0, 8, [64, 64]), D.VPSDE(), no_sigma=True).eval()
     with pytest.raises(RuntimeError, match="GPU"):
         sm.sample_ode_from_base(torch.randn(8, 4), method="rk4", options={"step_size": 0.1})
+    with pytest.raises(RuntimeError, match="GPU"):
+        sm.sample_ode_from_base(torch.randn(8, 4))                # reference default method=dopri5 (adaptive)
     with pytest.raises(NotImplementedError, match="adaptive"):
-        sm.sample_ode_from_base(torch.randn(8, 4))                # reference default method=dopri5
+        sm.sample_ode_from_base(torch.randn(8, 4), method="dopri8")
     with pytest.raises(NotImplementedError):
         D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Tanh()), D.VPSDE()).eval() \
             .sample_ode_from_base(torch.randn(8, 4), method="euler")
     f = F.ODEFlow(3, [64, 64])
-    with pytest.raises(NotImplementedError):
-        f.sample(torch.randn(4, 3))                              # adaptive default, as in the reference
+    with pytest.raises(RuntimeError, match="GPU"):
+        f.sample(torch.randn(4, 3))                              # adaptive dopri5 default, as in the reference
     with pytest.raises(RuntimeError, match="GPU"):
         f.sample(torch.randn(4, 3), method="rk4", options={"step_size": 0.1})
 
@@ -255,3 +257,71 @@ def test_emulated_tile16_packing_matches_oracle(built_library):
     xn = (xT - f.target_shift) / f.target_scale
     xTT, logj = E.emulate(planh, net.wpack("cpu", MODE_HUTCH), table, xn, cond=f._norm_cond(cond), probe=e, mode=MODE_HUTCH)
     assert torch.isfinite(logj).all() and xTT.shape == xn.shape
+
+
+# ---- adaptive dopri5 driver (host logic) against the oracle's independent restatement -------------------
+def _cpu_launcher(net, mode, cond=None, probe=None):
+    plan = _native.plan_words(net.plan(mode))
+    wpack = net.wpack("cpu", mode)
+    return lambda y, k1, kl1, lp0, etab, n_aux, first, count: E.emulate_step(
+        plan, wpack, etab, y, cond, probe, k1, kl1, lp0, mode, n_aux, first, count)
+
+
+@pytest.mark.parametrize("case", ["ve_sample", "ve_hutch", "vp_exact_cond"])
+def test_adaptive_dopri5_driver_matches_oracle(case, built_library):
+    from flowfusion_amd import adaptive
+    torch.manual_seed(3)
+    if case == "ve_sample":
+        meta = dict(D=6, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=True)
+    elif case == "ve_hutch":
+        meta = dict(D=3, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=False)
+    else:
+        meta = dict(D=4, C=2, E=8, units=[64], sde="VPSDE", sde_kw={}, no_sigma=False)
+    m = D.MLP(meta["D"], meta["C"], meta["E"], meta["units"])
+    sm = D.ScoreModel(m, getattr(D, meta["sde"])(), no_sigma=meta["no_sigma"]).eval()
+    arrays = {k: v.detach().clone() for k, v in sm.state_dict().items()}
+    so = score_oracle(meta, arrays)
+    net = sm._net()
+    B = 7
+    x = torch.randn(B, meta["D"])
+    cond = torch.randn(B, meta["C"]) if meta["C"] else None
+    eps = float(sm.sde.epsilon)
+    rtol = atol = 1e-5
+    # two adaptive solves agree to about the solver tolerance, not to rounding: a last-bit difference
+    # in one error norm can move every later step
+    TOL = 5e-5
+    sched = lambda tr: sm._schedule(tr, "ode")[:3]
+    if case == "ve_sample":
+        x = x * sm.sde.sigma_max
+        step = net.make_step(sched, -1.0, MODE_STATE, "cpu", launcher=_cpu_launcher(net, MODE_STATE))
+        solver = adaptive.Dopri5(step, False, rtol, atol, None)
+        t = torch.tensor([1.0, eps]).double()
+        y, _ = solver.integrate(float(-t[0]), float(-t[1]), x, None)
+        ref = so.sample_ode_from_base(x / sm.sde.sigma_max, None, "dopri5", None, atol, rtol)
+        assert solver.n_accepted >= 3
+        assert max_rel(y, ref, floor=ref.abs().max().item()) < TOL
+    else:
+        mode = MODE_HUTCH if case == "ve_hutch" else MODE_EXACT
+        e = torch.sign(torch.randn(B, meta["D"])) if mode == MODE_HUTCH else None
+        step = net.make_step(sched, 1.0, mode, "cpu", cond=cond, probe=e, launcher=_cpu_launcher(net, mode, cond, e))
+        solver = adaptive.Dopri5(step, True, rtol, atol, {"min_step": 1e-6})
+        y, lp = solver.integrate(eps if False else float(torch.tensor(eps, dtype=torch.float32)), 1.0, x, torch.zeros(B))
+        xT, dlp = so.solve_odes_forward(x, cond, "dopri5", {"min_step": 1e-6}, "hutch" if mode == MODE_HUTCH else "exact",
+                                        e, atol, rtol)
+        assert solver.n_accepted >= 3
+        assert max_rel(y, xT, floor=xT.abs().max().item()) < TOL
+        assert max_rel(lp[:, None], dlp, floor=1.0) < TOL
+
+
+def test_adaptive_nan_error_estimate_raises_like_torchdiffeq(built_library):
+    """VP schedules are undefined for t < 0; an overshooting last step makes the error estimate NaN,
+    upon which torchdiffeq asserts ('underflow in dt nan').  The driver must not spin."""
+    from flowfusion_amd import adaptive
+    torch.manual_seed(3)
+    sm = D.ScoreModel(D.MLP(6, 0, 8, [64, 64]), D.VPSDE(), no_sigma=True).eval()
+    net = sm._net()
+    step = net.make_step(lambda tr: sm._schedule(tr, "ode")[:3], -1.0, MODE_STATE, "cpu",
+                         launcher=_cpu_launcher(net, MODE_STATE))
+    solver = adaptive.Dopri5(step, False, 1e-5, 1e-5, None)
+    with pytest.raises(RuntimeError, match="underflow in dt"):
+        solver.integrate(-1.0, -0.001, torch.randn(7, 6), None)
