@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
     ap.add_argument("--cpu-batch", type=int, default=16384, help="samples for the CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,13 +106,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU path to time)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     sm = build_model(device)
     eps = float(sm.sde.epsilon)
@@ -116,12 +124,13 @@ def main():
     B = args.batch
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     z = torch.randn(B, DIM, device=device, generator=gen)
-    gathered = torch.empty(world * B, DIM, device=device) if world > 1 else None
+    gather_dev = device if args.backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * B, DIM, device=gather_dev) if world > 1 else None
 
     def step():
         x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, x)
+        if world > 1:      # the single collective of the path: all shards meet on every rank
+            dist.all_gather_into_tensor(gathered, x if args.backend == "nccl" else x.cpu())
         return x
 
     def barrier():
@@ -145,7 +154,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=gather_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -190,8 +199,10 @@ def main():
                          "hbm_frac_of_8TBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
-        if traffic_file.exists():
-            out["roofline"]["traffic"] = json.loads(traffic_file.read_text()).get("bytes_per_launch")
+        if traffic_file.exists():      # PMC measurement of this kernel at this batch (profiles/r01), per launch
+            tf = json.loads(traffic_file.read_text())
+            if tf.get("batch") == B and kernel_name.split("_m")[-1].split("_")[0] in tf.get("kernel", ""):
+                out["roofline"]["traffic"] = tf.get("bytes_per_launch")
         if args.cpu_batch > 0:
             ref, zc, cb = cpu_baseline(sm, args.cpu_batch, opts)
             out["cpu_baseline"] = cb
