@@ -226,6 +226,7 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
             }
         }
         constexpr int nxt = c + RING;
+#ifndef FF_DEBUG_NO_WLOADS      // timing experiment only: never refill the ring (wrong results)
         static_for<T::PHYS>([&](auto pp) {
             constexpr int p = decltype(pp)::value;
             if constexpr (WRAP && nxt >= L.CPAD)
@@ -233,6 +234,7 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
             else
                 ring[slot][p] = sload(ws, lane16, sbyte + nxt * CB + p * 1024);
         });
+#endif
         // Pin the stream order: MFMAs and vector-memory loads may not be scheduled across this
         // point (VALU / SALU / transcendental / DS work of the activations may), so every load
         // is issued exactly one ring length ahead of its use.

@@ -8,10 +8,10 @@
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 int main(int argc, char** argv)
 {
-    const int H = 256, DREGS = 8, NH = 4, D = 16;
+    const int TILE = 16, H = 256, DREGS = 4, NH = 4, D = 16;
     long long B = argc > 1 ? atoll(argv[1]) : (1 << 18);
     int n_evals = argc > 2 ? atoi(argv[2]) : 100;
-    ff::Layout L = ff::make_layout(H, DREGS, 0, NH);
+    ff::Layout L = ff::make_layout(TILE, H, DREGS, 0, NH);
     std::vector<float> hw(L.total_floats);
     srand(3);
     for (auto& v : hw) v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.12f;
@@ -33,10 +33,10 @@ int main(int argc, char** argv)
     ff::KernelArgs a; memset(&a, 0, sizeof(a));
     a.x_in = dx; a.x_out = dy; a.wpack = dw; a.etab = dt; a.batch = B; a.n_evals = n_evals; a.n_hidden = NH; a.dim = D;
     a.etab_stride = stride; a.wpack_floats = (int)L.total_floats; a.debug_stamps = dbg;
-    auto kern = ff::mlp_ode_kernel<256, 8, 0, false>;
+    auto kern = ff::mlp_ode_kernel<16, 256, 4, 0, false, 2, 8>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    unsigned lds = 4u * 6 * (DREGS / 4) * 64 * 16;
-    unsigned grid = (unsigned)((B + 127) / 128);
+    unsigned lds = 4u * ff::kSlots * (DREGS / 4) * 64 * 16;
+    unsigned grid = (unsigned)((B + 63) / 64);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a); CK(hipDeviceSynchronize());
     float best = 1e30f;
