@@ -285,9 +285,21 @@ class ScoreModel(nn.Module):
                                      x.detach().to(torch.float32).contiguous(), lp0)
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
             return y, lp
-        table = self._ode_table(t_span, method, options, mode)
+        key = ("score-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode,
+               self.no_sigma, self._schedule_key())
+        table = net.cached_table(key, x.device, lambda: self._ode_table(t_span, method, options, mode))
         y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe)
         return y, (lp if mode != MODE_STATE else None)
+
+    def _schedule_key(self):
+        """Everything besides the first layer that the evaluation table depends on."""
+        sde = self.sde
+        vals = [type(sde).__name__]
+        for name in ("beta_min", "beta_max", "T", "epsilon", "sigma_min", "sigma_max"):
+            if hasattr(sde, name):
+                vals.append(float(getattr(sde, name)))
+        m = self.model
+        return tuple(vals) + (m.W.data_ptr(), m.W._version)
 
     @torch.no_grad()
     def sample_sde(self, shape, conditional=None, steps=100):

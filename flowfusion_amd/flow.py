@@ -85,7 +85,8 @@ class _FlowBase(nn.Module):
                                      x.detach().to(torch.float32).contiguous(), lp0)
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
             return y, lp
-        table = self._table(t_span, method, options, mode)
+        key = ("flow-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode)
+        table = net.cached_table(key, x.device, lambda: self._table(t_span, method, options, mode))
         y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
         return y, (lp if mode != MODE_STATE else None)
 

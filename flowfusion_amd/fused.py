@@ -44,6 +44,7 @@ class FusedNet:
                 raise NotImplementedError("Linear layers without bias are not supported")
         self._plans = {}
         self._wpack = None          # (key, device tensor)
+        self._tables = {}           # small cache of evaluation tables already on the device
 
     # -- plan / weights ---------------------------------------------------------------------
     def plan(self, mode: int) -> _native.PlanStruct:
@@ -102,6 +103,19 @@ class FusedNet:
             total = dl if total is None else total + dl
             status = st if first == 0 else (status | st)
         return y, total, status
+
+    def cached_table(self, key, device, build):
+        """Evaluation tables depend only on (time span, method, options, schedule parameters, first-layer
+        weights): keep the last few on the device so repeated solves skip the host work."""
+        l0 = self.linears[0]
+        full = (key, str(device), l0.weight.data_ptr(), l0.weight._version, l0.bias._version)
+        hit = self._tables.get(full)
+        if hit is None:
+            if len(self._tables) >= 8:
+                self._tables.pop(next(iter(self._tables)))
+            hit = build().to(device)
+            self._tables[full] = hit
+        return hit
 
     # -- adaptive stepping: one launch per attempted step (flowfusion_amd/adaptive.py) -----------
     def make_step(self, schedule, sign: float, mode: int, device, cond=None, probe=None, launcher=None):

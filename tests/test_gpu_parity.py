@@ -392,3 +392,30 @@ def test_default_arguments_flows_and_wrappers():
     assert torch.equal(out, ref * pm.scale + pm.shift)
     s = pm.sample_sde((20, 3), steps=5)                       # `steps` is ignored by the reference wrapper: 100
     assert s.shape == (20, 3) and torch.isfinite(s).all()
+
+
+def test_caches_follow_parameter_updates():
+    """Packed weights and evaluation tables are cached on the device; an in-place parameter update
+    (optimizer step, load_state_dict) must invalidate them."""
+    sm, _, _ = _seeded_score_model(16, 0, [64, 64], "VPSDE", True, 71)
+    opts = {"step_size": 0.1}
+    z = torch.randn(64, 16, device=DEV)
+    a, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    a2, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    assert torch.equal(a, a2)
+    with torch.no_grad():
+        sm.model.NN[0].weight.mul_(1.05)          # first layer: feeds both the packed stream and c1
+        sm.model.NN[1].bias.add_(0.01)
+    b, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    assert not torch.equal(a, b)
+    import copy
+    fresh = copy.deepcopy(sm)
+    fresh._fused = None
+    c, _ = fresh.sample_ode_from_base(z, method="rk4", options=opts)
+    assert torch.equal(b, c)
+    sd = {k: v.clone() for k, v in sm.state_dict().items()}
+    with torch.no_grad():
+        sm.model.NN[2].weight.zero_()
+    sm.load_state_dict(sd)
+    d, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    assert torch.equal(b, d)
