@@ -203,7 +203,7 @@ def main():
             tf = json.loads(traffic_file.read_text())
             if tf.get("batch") == B and kernel_name.split("_m")[-1].split("_")[0] in tf.get("kernel", ""):
                 out["roofline"]["traffic"] = tf.get("bytes_per_launch")
-        if args.cpu_batch > 0:
+        if args.cpu_batch > 0 and world == 1:      # CPU baseline and oracle parity: rank 0 of the 1-GPU run only
             ref, zc, cb = cpu_baseline(sm, args.cpu_batch, opts)
             out["cpu_baseline"] = cb
             # parity of the timed configuration: GPU vs oracle on the same base samples

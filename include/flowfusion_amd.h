@@ -156,6 +156,13 @@ int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* 
 
 /*
  * Enqueue the fused integration on `hip_stream` (a hipStream_t; NULL = default stream).
+ * Replaces, per mode and table (see the header comment and INTEGRATION.md):
+ *   odeint(self, (z,), t, method, ...)                     diffusion.py:631-639   FF_MODE_STATE
+ *   odeint(self, (x0, delta_logpx), t, method, ...)        diffusion.py:744-752   FF_MODE_HUTCH / FF_MODE_EXACT
+ *   the Euler-Maruyama loop of sample_sde                  diffusion.py:543-562   FF_MODE_STATE + FF_ROW_NOISE rows
+ *   odeint(self.dynamics, (xT[, cond]), t)                 flow.py:299-303, 792-796            FF_MODE_STATE
+ *   odeint(self.dynamics_with_jacobian, (x[, cond], logJ)) flow.py:371-382, 869-881            FF_MODE_EXACT
+ * Returns FF_OK once enqueued; on any error nothing is enqueued.
  */
 int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* args, void* hip_stream);
 
