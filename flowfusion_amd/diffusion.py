@@ -335,20 +335,47 @@ class ScoreModel(nn.Module):
         cout[:, 0] = dt                               # x_mean = x + f dt  (:557)
         zeros8 = torch.zeros(n, 8)
         slot = torch.zeros(n, dtype=torch.int32)
-        # noise slabs are drawn per step, in order -- chunked over steps to bound memory
+        # Noise slabs are drawn per step, in order, chunked over steps to bound memory.  The draws
+        # of chunk c+1 are enqueued on a side stream while the kernel integrates chunk c (two
+        # buffers), so the random-number kernels stay off the critical path; the host-side generator
+        # is advanced in the same order either way, so the stream of numbers is unchanged.
         per_step = max(batch * x.shape[1], 1)
-        chunk = max(1, min(n, (1 << 29) // per_step))
-        status_any = None
-        for start in range(0, n, chunk):
-            stop = min(n, start + chunk)
-            noise = torch.empty(stop - start, batch, x.shape[1], device=dev, dtype=torch.float32)
-            for i in range(stop - start):             # one draw per executed step, the last included (:554)
-                noise[i] = draw(x)
+        chunk = max(1, min(n, (1 << 28) // per_step))
+        bounds = [(s0, min(n, s0 + chunk)) for s0 in range(0, n, chunk)]
+        tables = []
+        for start, stop in bounds:
             sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=slot[start:stop], flags=flags[start:stop],
                                    cin=zeros8[start:stop], cout=cout[start:stop], n_steps=stop - start)
-            table = solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
-                                        gn=gn[start:stop], noise_idx=torch.arange(stop - start))
-            x, _, status = net.integrate(x, table, MODE_STATE, cond=conditional, noise=noise)
+            tables.append(solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
+                                              gn=gn[start:stop], noise_idx=torch.arange(stop - start)).to(dev))
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        bufs = [torch.empty(min(chunk, n), batch, x.shape[1], device=dev, dtype=torch.float32)
+                for _ in range(min(2, len(bounds)))]
+        ready = [None] * len(bounds)
+        freed = [None] * len(bufs)
+
+        def fill(c):
+            start, stop = bounds[c]
+            buf = bufs[c % len(bufs)]
+            with torch.cuda.stream(side):
+                if freed[c % len(bufs)] is not None:
+                    side.wait_event(freed[c % len(bufs)])       # the kernel that read this buffer is done
+                else:
+                    side.wait_stream(main)
+                for i in range(stop - start):                   # one draw per executed step, the last included (:554)
+                    buf[i] = draw(x)
+                ready[c] = side.record_event()
+
+        fill(0)
+        status_any = None
+        for c, (start, stop) in enumerate(bounds):
+            if c + 1 < len(bounds):
+                fill(c + 1)
+            main.wait_event(ready[c])
+            buf = bufs[c % len(bufs)]
+            x, _, status = net.integrate(x, tables[c], MODE_STATE, cond=conditional, noise=buf[: stop - start])
+            freed[c % len(bufs)] = main.record_event()
             status_any = status if status_any is None else (status_any | status)
         if int(status_any.item()) & 1:
             print("Diffusion is not stable, NaN were produced. Stopped sampling.")
