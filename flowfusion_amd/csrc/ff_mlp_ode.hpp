@@ -213,7 +213,11 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], T::zero());
                     else
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], acc[ob].v[p]);
-                    slot_fn(std::integral_constant<int, (4 * c + q) * T::PHYS + p>{}, acc);
+                    // activation stages only ever hang on the head of a layer (the previous layer's
+                    // parked block) and on phase B; skipping the call elsewhere saves the compiler
+                    // tens of thousands of empty template instantiations
+                    constexpr int M = (4 * c + q) * T::PHYS + p;
+                    if constexpr (phase_b || M < (16 + kActStages) * T::PHYS) slot_fn(std::integral_constant<int, M>{}, acc);
                 });
             });
             if constexpr (c == L.NC - 1) {

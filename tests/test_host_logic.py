@@ -46,7 +46,7 @@ def test_plan_selection_and_errors(built_library):
     p = _native.make_plan(32, 8, [200, 100], MODE_STATE)          # ragged widths pad to the max
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
     p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
-    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 512, 16, 0)
+    assert (p.tile, p.width, p.dregs) == (16, 512, 16)
     p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
     assert p.tile == 16 and _native.samples_per_workgroup(p, MODE_EXACT) == 4
     with pytest.raises(NotImplementedError):
