@@ -449,3 +449,44 @@ def test_launch_is_graph_capturable_and_stream_ordered():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, ref)
+
+
+def test_full_size_config4_and_config5_properties():
+    """Size-independent properties at the per-GPU share of BASELINE configs 4 and 5."""
+    from flowfusion_amd import flow as Fm
+    # config 4: 64-dim flow, 5x512, 2^22 samples over 8 GPUs = 2^19 per GPU
+    torch.manual_seed(91)
+    f = Fm.ODEFlow(64, [512] * 5).to(DEV).eval()
+    B = 1 << 19
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xT = torch.randn(B, 64, device=DEV, generator=g)
+    opts = {"step_size": 1.0 / 10}
+    x = f.sample(xT, method="rk4", options=opts)
+    assert torch.isfinite(x).all()
+    assert torch.equal(x, f.sample(xT, method="rk4", options=opts))                      # deterministic
+    for sl in (slice(0, 100), slice(B - 77, B)):                                          # batch-shape invariant
+        assert torch.equal(f.sample(xT[sl].contiguous(), method="rk4", options=opts), x[sl])
+    fo = flow_oracle({k: v.detach().cpu().clone() for k, v in f.state_dict().items()})
+    idx = torch.arange(0, B, B // 16)
+    assert _state_err(x[idx], fo.sample(xT[idx].cpu(), None, "rk4", opts)) < STATE_TOL
+    # reversibility: integrating the samples forward in time returns the base points
+    back, _ = f._solve(x, torch.tensor([0.0, 1.0]), "rk4", opts, 0, 1e-5, 1e-5)
+    assert ((back - xT).abs().max() / xT.abs().max()).item() < 1e-3
+    # config 5: conditional 32-dim VE, 4x256, Euler-Maruyama (100 of the 1000 steps), 2^17 samples
+    sm, so32, _ = _seeded_score_model(32, 8, [256] * 4, "VESDE", False, 92)
+    Bs = 1 << 17
+    cond = torch.randn(Bs, 8, device=DEV, generator=g)
+    torch.manual_seed(17)
+    a = sm.sample_sde((Bs, 32), conditional=cond, steps=100)
+    torch.manual_seed(17)
+    b = sm.sample_sde((Bs, 32), conditional=cond, steps=100)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    # the first rows of the batch, re-run alone with the same draws, give the same bits
+    torch.manual_seed(17)
+    prior = sm.sde.prior([32]).sample([Bs]).to(DEV)
+    draws = [torch.randn_like(prior) for _ in range(100)]
+    it = iter(d[:300].contiguous() for d in draws)
+    small = sm._sample_sde_from(prior[:300].contiguous(), lambda like: next(it), cond[:300].contiguous(), steps=100)
+    assert torch.equal(small, a[:300])
+    ref = so32.sample_sde(prior[:64].cpu(), [d[:64].cpu() for d in draws], cond[:64].cpu(), steps=100)
+    assert _state_err(a[:64], ref) < STATE_TOL
