@@ -23,6 +23,9 @@ MODE_STATE = 0
 MODE_HUTCH = 1
 MODE_EXACT = 2
 
+# FF_ACT_* of include/flowfusion_amd.h
+ACT_SILU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SOFTPLUS, ACT_GELU, ACT_GELU_TANH = range(9)
+
 _LIB_PATH = Path(__file__).resolve().parent / "lib" / "libflowfusion_amd.so"
 
 
@@ -36,6 +39,9 @@ class PlanStruct(ctypes.Structure):
         ("cregs", ctypes.c_int32),
         ("kernel_id", ctypes.c_int32),
         ("tile", ctypes.c_int32),
+        ("activation", ctypes.c_int32),
+        ("act_param", ctypes.c_float * 2),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -95,6 +101,10 @@ def lib() -> ctypes.CDLL:
     L.ff_mlp_plan.restype = ctypes.c_int
     L.ff_mlp_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                               ctypes.c_int, ctypes.POINTER(PlanStruct)]
+    L.ff_mlp_plan_act.restype = ctypes.c_int
+    L.ff_mlp_plan_act.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                  ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                  ctypes.POINTER(PlanStruct)]
     L.ff_mlp_wpack_floats.restype = ctypes.c_size_t
     L.ff_mlp_wpack_floats.argtypes = [ctypes.POINTER(PlanStruct)]
     L.ff_mlp_wpack.restype = ctypes.c_int
@@ -116,14 +126,17 @@ def _err(rc: int, what: str) -> RuntimeError:
     return RuntimeError(f"{what} failed: {names.get(rc, rc)}{extra}")
 
 
-def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int) -> PlanStruct:
-    """ff_mlp_plan: pick the compiled kernel for this network shape (raises if none fits)."""
+def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
+              act: Tuple[int, float, float] = (ACT_SILU, 0.0, 0.0)) -> PlanStruct:
+    """ff_mlp_plan_act: pick the compiled kernel for this network shape (raises if none fits)."""
     p = PlanStruct()
     arr = (ctypes.c_int * len(hidden))(*hidden)
-    rc = lib().ff_mlp_plan(dim, cond_dim, len(hidden), arr, mode, ctypes.byref(p))
+    prm = (ctypes.c_float * 2)(float(act[1]), float(act[2]))
+    rc = lib().ff_mlp_plan_act(dim, cond_dim, len(hidden), arr, mode, int(act[0]), prm, ctypes.byref(p))
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
-            f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}: "
+            f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
+            f"activation={act[0]}: "
             "compiled shapes cover dim<=32 / cond_dim<=16 / hidden width<=256 (32x32x2 kernels) and "
             "dim<=64 / cond_dim<=16 / width<=512 (16x16x4 kernels)")
     if rc != FF_OK:
@@ -152,12 +165,16 @@ def samples_per_workgroup(plan: PlanStruct, mode: int) -> int:
     return int(lib().ff_mlp_samples_per_workgroup(ctypes.byref(plan), mode))
 
 
+_PLAN_WORDS = ctypes.sizeof(PlanStruct) // 4
+
+
 def _plan_from_words(words: List[int]) -> PlanStruct:
-    return PlanStruct(*words)
+    return PlanStruct.from_buffer_copy((ctypes.c_int32 * _PLAN_WORDS)(*words))
 
 
 def plan_words(plan: PlanStruct) -> List[int]:
-    return [int(getattr(plan, f)) for f, _ in PlanStruct._fields_]
+    """The plan as 32-bit words (how it travels through the custom op's integer-list argument)."""
+    return list((ctypes.c_int32 * _PLAN_WORDS).from_buffer_copy(plan))
 
 
 def _chk(t: Optional[torch.Tensor], name: str, dev) -> int:

@@ -39,7 +39,17 @@ static int tangents_of_mode(int mode, int dim, int tile, int* n_tangent, int* un
 extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
                            ff_mlp_plan_t* plan)
 {
+    return ff_mlp_plan_act(dim, cond_dim, n_hidden, hidden_widths, mode, FF_ACT_SILU, NULL, plan);
+}
+
+extern "C" int ff_mlp_plan_act(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                               int activation, const float* act_param, ff_mlp_plan_t* plan)
+{
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
+    if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
+    // FF_ANY_ACT=1 sends SiLU networks to the run-time-activation kernels as well (A/B tests)
+    const char* force_any = getenv("FF_ANY_ACT");
+    const int need_any = (activation != FF_ACT_SILU || (force_any && atoi(force_any))) ? 1 : 0;
     if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     int wmax = 0;
     for (int i = 0; i < n_hidden; ++i) {
@@ -57,7 +67,7 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
         const ff::KernelEntry& k = ff::g_kernels[i];
         const int need_d = ff::regs_for(k.tile, dim);
         const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
-        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t) continue;
+        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t || k.any_act != need_any) continue;
         if (pin_tile && k.tile != pin_tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
@@ -75,6 +85,8 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
     plan->cregs = ff::g_kernels[best].cregs;
     plan->kernel_id = best;
     plan->tile = ff::g_kernels[best].tile;
+    plan->activation = activation;
+    if (act_param) { plan->act_param[0] = act_param[0]; plan->act_param[1] = act_param[1]; }
     return FF_OK;
 }
 
@@ -84,6 +96,7 @@ static bool plan_ok(const ff_mlp_plan_t* p)
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
     const int per_reg = 64 / k.tile;
     return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
+           p->activation >= 0 && p->activation < FF_ACT_COUNT && (p->activation == FF_ACT_SILU || k.any_act) &&
            p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
 }
 
@@ -201,6 +214,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
     ka.k1_in = a->k1_in; ka.kl1_in = a->kl1_in; ka.dlogp_in = a->dlogp_in; ka.n_aux = a->n_aux;
     for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
+    ka.act_kind = plan->activation; ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;

@@ -40,6 +40,8 @@ struct KernelArgs {
     float* aux_out[kAux];
     float* aux_lp_out[kAux];
     int n_aux;
+    int act_kind;        // FF_ACT_* (read by the run-time-activation instantiations only)
+    float act_p0, act_p1;
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
 };
 

@@ -131,10 +131,124 @@ struct ActGroup {
     float pre[4], t[4], r[4], h[4];
     int dv[4];
 };
-template <bool TANGENTS, int STAGE>
-__device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, bool is_tangent,
-                                          int value_lane_bytes)
+// Activation selected at run time (instantiations with GENERIC_ACT; include/flowfusion_amd.h FF_ACT_*).
+struct ActSpec {
+    int kind;
+    float p0, p1;
+};
+// value h = act(a) and slope d = act'(a) of 4 pre-activations.  `kind` is wave-uniform (an SGPR), so
+// the switch is a scalar branch around straight-line code.
+__device__ __forceinline__ void act_generic(const ActSpec& s, const float (&a)[4], float (&h)[4], float (&d)[4])
 {
+    constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+    switch (s.kind) {
+    default:   // FF_ACT_SILU
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * -LOG2E));
+            h[i] = a[i] * r;
+            d[i] = __builtin_fmaf(h[i], 1.0f - r, r);
+        }
+        break;
+    case 1:    // tanh(a) = 2 sigmoid(2a) - 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * (-2.0f * LOG2E)));
+            h[i] = __builtin_fmaf(2.0f, r, -1.0f);
+            d[i] = __builtin_fmaf(-h[i], h[i], 1.0f);
+        }
+        break;
+    case 2:    // sigmoid
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * -LOG2E));
+            h[i] = r;
+            d[i] = r * (1.0f - r);
+        }
+        break;
+    case 3:    // relu
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = a[i] > 0.f ? a[i] : 0.f;
+            d[i] = a[i] > 0.f ? 1.f : 0.f;
+        }
+        break;
+    case 4:    // leaky relu, p0 = negative slope
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = a[i] > 0.f ? a[i] : a[i] * s.p0;
+            d[i] = a[i] > 0.f ? 1.f : s.p0;
+        }
+        break;
+    case 5:    // elu, p0 = alpha
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = __builtin_amdgcn_exp2f(fminf(a[i], 0.f) * LOG2E);
+            h[i] = a[i] > 0.f ? a[i] : s.p0 * (e - 1.0f);
+            d[i] = a[i] > 0.f ? 1.f : s.p0 * e;
+        }
+        break;
+    case 6:    // softplus, p0 = beta, p1 = threshold:  log(1 + exp(beta a)) / beta, linear above the threshold
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float z = a[i] * s.p0;
+            const float e = __builtin_amdgcn_exp2f(-fabsf(z) * LOG2E);
+            const float r = __builtin_amdgcn_rcpf(1.0f + e);
+            const float sp = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), LN2, fmaxf(z, 0.f));
+            const bool lin = z > s.p1;
+            h[i] = lin ? a[i] : sp / s.p0;
+            d[i] = lin ? 1.f : (z >= 0.f ? r : e * r);
+        }
+        break;
+    case 7:    // gelu (erf form): a Phi(a); erf by Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u = fabsf(a[i]) * 0.70710678118654752440f;
+            const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, u, 1.0f));
+            const float g = __builtin_amdgcn_exp2f(-u * u * LOG2E);                    // exp(-a^2/2)
+            float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+            poly = __builtin_fmaf(poly, t, 1.421413741f);
+            poly = __builtin_fmaf(poly, t, -0.284496736f);
+            poly = __builtin_fmaf(poly, t, 0.254829592f);
+            const float erfc_u = poly * t * g;                                         // 1 - erf(u), u >= 0
+            const float phi = a[i] >= 0.f ? 1.0f - 0.5f * erfc_u : 0.5f * erfc_u;      // Phi(a)
+            h[i] = a[i] * phi;
+            d[i] = __builtin_fmaf(a[i] * 0.39894228040143267794f, g, phi);
+        }
+        break;
+    case 8:    // gelu, tanh form: a sigmoid(2 w), w = sqrt(2/pi) (a + 0.044715 a^3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a2 = a[i] * a[i];
+            const float w = 0.79788456080286535588f * a[i] * __builtin_fmaf(0.044715f, a2, 1.0f);
+            const float dw = 0.79788456080286535588f * __builtin_fmaf(3.0f * 0.044715f, a2, 1.0f);
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w * (-2.0f * LOG2E)));
+            h[i] = a[i] * r;
+            d[i] = __builtin_fmaf(2.0f * dw * h[i], 1.0f - r, r);
+        }
+        break;
+    }
+}
+template <bool TANGENTS, bool GENERIC_ACT, int STAGE>
+__device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, bool is_tangent,
+                                          int value_lane_bytes, const ActSpec& spec)
+{
+    if constexpr (GENERIC_ACT) {
+        // run-time activation: not latency-tuned -- value and slope are computed in one piece in stage 3
+        // (short live ranges), the cross-lane fetch of the slope follows at once and is consumed in stage 4
+        if constexpr (STAGE == 3) {
+            act_generic(spec, g.pre, g.h, g.r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (TANGENTS) g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, g.r[i]));
+                else dst[i] = g.h[i];
+            }
+        } else if constexpr (STAGE == 4 && TANGENTS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = is_tangent ? __builtin_bit_cast(float, g.dv[i]) * g.pre[i] : g.h[i];
+        }
+        return;
+    }
     // scalar code on purpose: packed f32 VALU (v_pk_*) issued beside MFMAs costs more than it saves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -267,7 +381,7 @@ FF_HD constexpr int act_group_at(const LayerGeom& L, int phys, int gpb, int M, i
     return blk <= L.NOB - 2 ? blk * gpb + gi : -1;
 }
 
-template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING>
+template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, bool GENERIC_ACT = false>
 __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args)
 {
     static_assert(kChunkPad % RING == 0, "ring must divide the chunk padding");
@@ -289,6 +403,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int D = args.dim;
     const int C = args.cond_dim;
+    const ActSpec aspec = {args.act_kind, args.act_p0, args.act_p1};
 
     // ---- column roles -----------------------------------------------------------------
     long long sample;
@@ -457,7 +572,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ag[gi].pre[i] = pend[4 * gi + i];
                     }
-                    act_stage<TANGENTS, k>(ag[gi], &P[(NB - 1) * RB + 4 * gi], is_tangent, value_lane_bytes);
+                    act_stage<TANGENTS, GENERIC_ACT, k>(ag[gi], &P[(NB - 1) * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
                 }
             });
         };
@@ -475,7 +590,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                         for (int i = 0; i < 4; ++i)
                             ag[4 + id % 8].pre[i] = acc[blk].reg(4 * gi + i) + bias1(bias[blk & 1], 4 * gi + i);
                     }
-                    act_stage<TANGENTS, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes);
+                    act_stage<TANGENTS, GENERIC_ACT, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
                 }
             });
         };

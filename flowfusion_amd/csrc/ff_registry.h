@@ -13,6 +13,7 @@ struct KernelEntry {
     int dregs;      // state registers  (covers dim <= dregs * 64/tile)
     int cregs;      // conditional registers
     int tangents;   // 1: divergence-capable instantiation
+    int any_act;    // 0: SiLU compiled in; 1: activation selected at run time (FF_ACT_*)
     LaunchFn launch;
     const char* name;
 };

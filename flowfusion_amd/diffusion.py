@@ -28,7 +28,7 @@ from torch import nn
 from torch.distributions import Normal
 
 from . import adaptive, solvers
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
 
 
 # ------------------------------------------------------------------------------------------------
@@ -229,11 +229,11 @@ class ScoreModel(nn.Module):
             raise NotImplementedError(
                 "the fused gfx950 path needs a flowfusion MLP score network "
                 f"(NN/W/pi attributes); got {type(m).__name__}")
-        _require_silu(m.activation)
-        if self._fused is None or self._fused.linears[0] is not m.NN[0]:
+        act = activation_spec(m.activation)
+        if self._fused is None or self._fused.linears[0] is not m.NN[0] or self._fused.act != act:
             E = 2 * m.W.numel()
             self._fused = FusedNet(list(m.NN), m.n_dimensions, m.n_conditionals, x_col0=E,
-                                   c_col0=E + m.n_dimensions)
+                                   c_col0=E + m.n_dimensions, act=act)
         return self._fused
 
     def _schedule(self, t: torch.Tensor, sde_form: str):

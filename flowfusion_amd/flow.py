@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import adaptive, solvers
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, _require_silu
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
 
 _DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
 
@@ -43,16 +43,17 @@ class _FlowBase(nn.Module):
         return [m for m in self.layers if isinstance(m, nn.Linear)]
 
     def _net(self) -> FusedNet:
-        for m in self.layers:
-            if not isinstance(m, nn.Linear):
-                _require_silu(m)
+        specs = {activation_spec(m) for m in self.layers if not isinstance(m, nn.Linear)}
+        if len(specs) != 1:
+            raise NotImplementedError("the fused gfx950 path needs one activation shared by all hidden layers")
+        act = next(iter(specs))
         lin = self._linears()
         cached = getattr(self, "_fused", None)
-        if cached is None or cached.linears[0] is not lin[0]:
+        if cached is None or cached.linears[0] is not lin[0] or cached.act != act:
             D = self.target_dimension
             C = getattr(self, "conditional_dimension", 0)
             # first-layer columns: [x (D) | t (1) | cond (C)]
-            object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1))
+            object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1, act=act))
         return self._fused
 
     def _schedule(self, t):

@@ -1,6 +1,6 @@
 """Shared host plumbing between the score-model and flow front ends.
 
-``FusedNet`` owns what the kernel needs from a Linear/SiLU stack: the kernel plan, the
+``FusedNet`` owns what the kernel needs from a Linear/activation stack: the kernel plan, the
 weights repacked into MFMA operand order (cached on the device, refreshed when a parameter
 changes) and the launch itself.  The front ends (diffusion.py, flow.py) supply the
 time-dependent part: one evaluation table per solve (solvers.py).
@@ -16,20 +16,42 @@ from . import _native
 from ._native import MODE_EXACT, MODE_HUTCH, MODE_STATE  # noqa: F401  (re-exported)
 
 
-def _require_silu(act) -> None:
-    ok = isinstance(act, nn.SiLU) or act is nn.SiLU
-    if not ok:
-        raise NotImplementedError(
-            f"activation {act!r}: the fused gfx950 kernels implement SiLU (the reference default, "
-            "diffusion.py:38, flow.py:41) only")
+def activation_spec(act) -> Tuple[int, float, float]:
+    """(FF_ACT_* code, parameter 0, parameter 1) of a torch.nn activation module or class -- the
+    `activation` argument of the reference constructors (an instance for MLP, diffusion.py:38; a class
+    for the flows, flow.py:41,70)."""
+    if isinstance(act, type):
+        act = act()
+    N = _native
+    if type(act) is nn.SiLU:
+        return (N.ACT_SILU, 0.0, 0.0)
+    if type(act) is nn.Tanh:
+        return (N.ACT_TANH, 0.0, 0.0)
+    if type(act) is nn.Sigmoid:
+        return (N.ACT_SIGMOID, 0.0, 0.0)
+    if type(act) is nn.ReLU:
+        return (N.ACT_RELU, 0.0, 0.0)
+    if type(act) is nn.LeakyReLU:
+        return (N.ACT_LEAKY_RELU, float(act.negative_slope), 0.0)
+    if type(act) is nn.ELU:
+        return (N.ACT_ELU, float(act.alpha), 0.0)
+    if type(act) is nn.Softplus:
+        return (N.ACT_SOFTPLUS, float(act.beta), float(act.threshold))
+    if type(act) is nn.GELU:
+        return (N.ACT_GELU_TANH if act.approximate == "tanh" else N.ACT_GELU, 0.0, 0.0)
+    raise NotImplementedError(
+        f"activation {act!r}: the fused gfx950 kernels implement SiLU (the reference default), Tanh, Sigmoid, "
+        "ReLU, LeakyReLU, ELU, Softplus and GELU")
 
 
 class FusedNet:
     """Kernel-side view of ``Linear -> SiLU -> ... -> Linear`` with first-layer input
     ``[ time part | x | cond ]`` in any column order."""
 
-    def __init__(self, linears: Sequence[nn.Linear], dim: int, cond_dim: int, x_col0: int, c_col0: int):
+    def __init__(self, linears: Sequence[nn.Linear], dim: int, cond_dim: int, x_col0: int, c_col0: int,
+                 act: Tuple[int, float, float] = (_native.ACT_SILU, 0.0, 0.0)):
         self.linears = list(linears)
+        self.act = (int(act[0]), float(act[1]), float(act[2]))
         if len(self.linears) < 2:
             raise NotImplementedError("the fused path needs at least one hidden layer")
         self.dim = int(dim)
@@ -50,7 +72,7 @@ class FusedNet:
     def plan(self, mode: int) -> _native.PlanStruct:
         key = 0 if mode == MODE_STATE else (1 if mode == MODE_HUTCH else 2)
         if key not in self._plans:
-            self._plans[key] = _native.make_plan(self.dim, self.cond_dim, self.hidden, mode)
+            self._plans[key] = _native.make_plan(self.dim, self.cond_dim, self.hidden, mode, self.act)
         return self._plans[key]
 
     def _param_key(self, device, plan) -> Tuple:

@@ -59,6 +59,21 @@ extern "C" {
                                    default: diffusion.py:483-503, flow.py:158-161); see
                                    ff_ode_args.tangent_first/count                          */
 
+/* Hidden-layer activation (the `activation` argument of the reference constructors,
+ * diffusion.py:38,77,118; flow.py:41,70; 478,518).  FF_ACT_SILU, the reference default, has
+ * instantiations of its own; the others run on instantiations that select the function at
+ * run time.  Values and slopes follow torch.nn's definitions. */
+#define FF_ACT_SILU        0    /* a * sigmoid(a)                                          */
+#define FF_ACT_TANH        1
+#define FF_ACT_SIGMOID     2
+#define FF_ACT_RELU        3
+#define FF_ACT_LEAKY_RELU  4    /* act_param[0] = negative_slope                           */
+#define FF_ACT_ELU         5    /* act_param[0] = alpha                                    */
+#define FF_ACT_SOFTPLUS    6    /* act_param[0] = beta, act_param[1] = threshold           */
+#define FF_ACT_GELU        7    /* a * Phi(a); erf by a 1.5e-7-accurate rational form      */
+#define FF_ACT_GELU_TANH   8    /* nn.GELU(approximate="tanh")                             */
+#define FF_ACT_COUNT       9
+
 /* evaluation-row flag bits (word 3 of the row header) */
 #define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */
 #define FF_ROW_NOISE       2u   /* after the step update: y += gn * noise[noise_index]     */
@@ -76,6 +91,9 @@ typedef struct ff_mlp_plan_t {
     int32_t cregs;       /* conditional registers per lane                                */
     int32_t kernel_id;   /* index into the compiled instantiation table                   */
     int32_t tile;        /* MFMA columns per wavefront: 32 (32x32x2 f32) or 16 (16x16x4)  */
+    int32_t activation;  /* FF_ACT_*                                                      */
+    float   act_param[2];/* parameters of the activation (see FF_ACT_*), else 0           */
+    int32_t reserved;
 } ff_mlp_plan_t;
 
 /* Arguments of one fused integration launch. */
@@ -135,6 +153,11 @@ const char* ff_kernel_name(int kernel_id);
  */
 int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
                 ff_mlp_plan_t* plan_out);
+
+/* The same for a network whose hidden layers use `activation` (FF_ACT_*) with parameters
+ * `act_param[2]` (NULL = zeros); ff_mlp_plan(...) is ff_mlp_plan_act(..., FF_ACT_SILU, NULL, ...). */
+int ff_mlp_plan_act(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                    int activation, const float* act_param, ff_mlp_plan_t* plan_out);
 
 /* Floats in the packed weight buffer of a plan. */
 size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan);

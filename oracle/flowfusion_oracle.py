@@ -59,9 +59,10 @@ def silu(x):
     return x * torch.sigmoid(x)
 
 
-def mlp_forward(p: MLPParams, t, x, conditional=None):
+def mlp_forward(p: MLPParams, t, x, conditional=None, activation=silu):
     """diffusion.py:82-121 -- concat conditional, broadcast scalar t, Gaussian-Fourier features
-    ``t*W*2*pi`` (in that order), ``[sin, cos, x]``, Linear/SiLU stack, final Linear."""
+    ``t*W*2*pi`` (in that order), ``[sin, cos, x]``, Linear/activation stack, final Linear.
+    ``activation`` is the constructor's ``activation`` module (diffusion.py:38,77; default SiLU)."""
     if conditional is not None:
         x = torch.cat([x, conditional], dim=1)                      # :101-102
     if t.dim() == 0:
@@ -69,7 +70,7 @@ def mlp_forward(p: MLPParams, t, x, conditional=None):
     t_proj = t[:, None] * p.W[None, :] * 2 * p.pi                   # :109
     h = torch.cat([torch.sin(t_proj), torch.cos(t_proj), x], dim=1)  # :110-113
     for w, b in zip(p.weights[:-1], p.biases[:-1]):                  # :116-118
-        h = silu(torch.nn.functional.linear(h, w, b))
+        h = activation(torch.nn.functional.linear(h, w, b))
     return torch.nn.functional.linear(h, p.weights[-1], p.biases[-1])   # :119
 
 
@@ -167,14 +168,15 @@ def normal_log_prob(x, scale):
 class ScoreOracle:
     """diffusion.py:124-815 restated over plain tensors."""
 
-    def __init__(self, params: MLPParams, sde, no_sigma=False, dtype=torch.float32):
+    def __init__(self, params: MLPParams, sde, no_sigma=False, dtype=torch.float32, activation=silu):
         self.p = params.to(dtype)
         self.sde = sde
         self.no_sigma = no_sigma
         self.dtype = dtype
+        self.activation = activation                                 # MLP(activation=...), diffusion.py:38
 
     def score(self, t, x, conditional=None):                         # :233-238
-        out = mlp_forward(self.p, t, x, conditional)
+        out = mlp_forward(self.p, t, x, conditional, self.activation)
         if self.no_sigma:
             return out
         return out / self.sde.sigma(t).view(-1, *[1] * len(x.shape[1:]))
@@ -506,15 +508,16 @@ def flow_params_from_state_dict(sd) -> FlowParams:
 class FlowOracle:
     """flow.py:9-438 (unconditional) and :441-941 (conditional) restated over plain tensors."""
 
-    def __init__(self, params: FlowParams, dtype=torch.float32):
+    def __init__(self, params: FlowParams, dtype=torch.float32, activation=silu):
         self.p = params.to(dtype)
         self.dtype = dtype
+        self.activation = activation                                  # one activation() per hidden layer, flow.py:70
         self.twopi = torch.tensor(2.0 * 3.14159265358979323846, dtype=torch.float32).to(dtype)   # flow.py:77
 
     def velocity(self, inputs):                                       # nn.Sequential, flow.py:68-74
         h = inputs
         for w, b in zip(self.p.weights[:-1], self.p.biases[:-1]):
-            h = silu(torch.nn.functional.linear(h, w, b))
+            h = self.activation(torch.nn.functional.linear(h, w, b))
         return torch.nn.functional.linear(h, self.p.weights[-1], self.p.biases[-1])
 
     def dynamics(self, t, x, conditional=None):

@@ -70,9 +70,25 @@ def decode_wpack(plan, wpack):
     return W1, hidden, Wo, bo, dx
 
 
-def _silu(a):
-    s = torch.sigmoid(a)
-    return a * s, s + a * s * (1 - s)
+def _act_fn(plan):
+    """(value, slope) of the plan's activation (plan words 8..10: FF_ACT_* code and two float parameters),
+    from torch's own definitions in float64."""
+    import struct
+    F = torch.nn.functional
+    kind = int(plan[8]) if len(plan) > 8 else 0
+    p0, p1 = (struct.unpack("f", struct.pack("i", int(plan[i])))[0] if len(plan) > i else 0.0 for i in (9, 10))
+    fn = {0: F.silu, 1: torch.tanh, 2: torch.sigmoid, 3: F.relu, 4: lambda a: F.leaky_relu(a, p0),
+          5: lambda a: F.elu(a, p0), 6: lambda a: F.softplus(a, p0, p1), 7: F.gelu,
+          8: lambda a: F.gelu(a, approximate="tanh")}[kind]
+
+    def act(a):
+        with torch.enable_grad():
+            a = a.detach().requires_grad_(True)
+            h = fn(a)
+            d, = torch.autograd.grad(h.sum(), a)
+        return h.detach(), d
+
+    return act
 
 
 def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp):
@@ -80,6 +96,7 @@ def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp):
     D, C, NH, H = plan[0], plan[1], plan[2], plan[3]
     W1, hidden, Wo, bo, dx = decode_wpack(plan, wpack)
     W1x, W1c = W1[:, :D], W1[:, dx:dx + C]
+    _silu = _act_fn(plan)
     etab64 = etab.double()
     ints = etab.contiguous().view(torch.int32)
     cc = cond.double() @ W1c.T if C else 0.0

@@ -490,3 +490,87 @@ def test_full_size_config4_and_config5_properties():
     assert torch.equal(small, a[:300])
     ref = so32.sample_sde(prior[:64].cpu(), [d[:64].cpu() for d in draws], cond[:64].cpu(), steps=100)
     assert _state_err(a[:64], ref) < STATE_TOL
+
+
+# ---- non-default activations (`activation=` of the reference constructors) -----------------------------------
+ACTIVATIONS = [torch.nn.Tanh(), torch.nn.Sigmoid(), torch.nn.ReLU(), torch.nn.LeakyReLU(0.2), torch.nn.ELU(0.7),
+               torch.nn.Softplus(), torch.nn.Softplus(beta=2.0, threshold=3.0), torch.nn.GELU(),
+               torch.nn.GELU(approximate="tanh")]
+KINKED = (torch.nn.ReLU, torch.nn.LeakyReLU, torch.nn.ELU)    # slope jumps at 0: divergence discontinuous in the state
+
+
+@pytest.mark.parametrize("act", ACTIVATIONS, ids=lambda a: repr(a))
+def test_activations_against_oracle(act):
+    """Every supported activation, on each of the run-time-activation kernels (widths 64/128/256/512):
+    sampling, Hutchinson and exact-trace log-density of a conditional VE score model, and a 40-dimensional
+    flow (exact trace in several passes), against the oracle run with the same torch module."""
+    from flowfusion_amd import diffusion as Dm, flow as Fm
+    from oracle import flowfusion_oracle as O
+    for units, D, C in (([64, 48], 5, 2), ([128] * 3, 12, 0), ([256] * 3, 16, 3)):
+        torch.manual_seed(31 + len(units) + D)
+        sm = Dm.ScoreModel(Dm.MLP(D, C, 8, units, activation=act), Dm.VESDE(), no_sigma=False).eval()
+        params = O.mlp_params_from_state_dict({k: v.detach().clone() for k, v in sm.state_dict().items()})
+        so32 = O.ScoreOracle(params, O.VE(), no_sigma=False, activation=act)
+        so64 = O.ScoreOracle(params, O.VE(dtype=torch.float64), no_sigma=False, dtype=torch.float64, activation=act)
+        sm = sm.to(DEV)
+        B = 150
+        base = torch.randn(B, D) * float(sm.sde.sigma_max)
+        cond = torch.randn(B, C) if C else None
+        cd = None if cond is None else cond.to(DEV)
+        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 25}
+        x0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cd, method="rk4", options=opts)
+        ref, _ = so32.sample_ode_from_base(base, cond, "rk4", opts)
+        assert _state_err(x0, ref) < STATE_TOL, (act, units)
+        xd = torch.randn(40, D)
+        cdd = None if cond is None else cond[:40]
+        e = torch.sign(torch.randn(40, D))
+        tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), "rk4", opts, 1)
+        xT, dlp, _ = sm._net().integrate(xd.to(DEV), tab, 1, cond=None if cdd is None else cdd.to(DEV), probe=e.to(DEV))
+        rx, rdl = so64.solve_odes_forward(xd.double(), None if cdd is None else cdd.double(), "rk4", opts, "hutch",
+                                          e.double())
+        assert _state_err(xT, rx.float()) < STATE_TOL, (act, units)
+        if not isinstance(act, KINKED):
+            assert _logp_err(dlp.view(-1), rdl.view(-1).float()) < LOGP_TOL, (act, units)
+            lp = sm.log_prob(xd.to(DEV), conditional=None if cdd is None else cdd.to(DEV), method="rk4", options=opts)
+            ref = so64.log_prob(xd.double(), None if cdd is None else cdd.double(), "rk4", opts, "exact")
+            assert _logp_err(lp, ref.float()) < LOGP_TOL, (act, units)
+    # flows take the activation as a class (flow.py:41,70); width 512, 40 dimensions
+    torch.manual_seed(77)
+    kw = {}
+    if isinstance(act, torch.nn.LeakyReLU) or isinstance(act, torch.nn.ELU) or repr(act) != repr(type(act)()):
+        cls = lambda: act                       # parameterised module: hand the configured instance to every layer
+    else:
+        cls = type(act)
+    f = Fm.ODEFlow(40, [512, 300], activation=cls, target_shift=torch.randn(40), target_scale=torch.rand(40) + 0.5).eval()
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    fo = O.FlowOracle(O.flow_params_from_state_dict(sd), activation=act)
+    fo64 = O.FlowOracle(O.flow_params_from_state_dict(sd), dtype=torch.float64, activation=act)
+    f = f.to(DEV)
+    xT = torch.randn(100, 40)
+    opts = {"step_size": 0.05}
+    got = f.sample(xT.to(DEV), method="rk4", options=opts)
+    assert _state_err(got, fo.sample(xT, None, "rk4", opts)) < STATE_TOL, act
+    if not isinstance(act, KINKED):
+        x = xT[:24] * f.target_scale.cpu() + f.target_shift.cpu()
+        lp = f.log_prob(x.to(DEV), method="rk4", options=opts)
+        assert _logp_err(lp, fo64.log_prob(x.double(), None, "rk4", opts).float()) < LOGP_TOL, act
+
+
+def test_silu_on_the_runtime_activation_kernels(monkeypatch):
+    """FF_ANY_ACT=1 routes SiLU networks to the run-time-activation kernels: same results as the SiLU
+    kernels (the two evaluate the same expression)."""
+    from flowfusion_amd import _native
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("FF_ANY_ACT", force)
+        sm, _, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 3)
+        name = _native.lib().ff_kernel_name(sm._net().plan(2).kernel_id)
+        assert (b"_act" in name) == (force == "1")
+        torch.manual_seed(8)
+        x = torch.randn(300, 16)
+        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
+        x0, _ = sm.sample_ode_from_base(x.to(DEV), method="rk4", options=opts)
+        lp = sm.log_prob(x[:64].to(DEV), method="rk4", options=opts)
+        outs.append((x0.cpu(), lp.cpu()))
+    assert _state_err(outs[1][0], outs[0][0]) < 1e-6
+    assert _logp_err(outs[1][1], outs[0][1]) < 1e-6

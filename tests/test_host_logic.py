@@ -68,7 +68,7 @@ def test_no_cpu_fallback(built_library):
     with pytest.raises(NotImplementedError, match="adaptive"):
         sm.sample_ode_from_base(torch.randn(8, 4), method="dopri8")
     with pytest.raises(NotImplementedError):
-        D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Tanh()), D.VPSDE()).eval() \
+        D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Mish()), D.VPSDE()).eval() \
             .sample_ode_from_base(torch.randn(8, 4), method="euler")
     f = F.ODEFlow(3, [64, 64])
     with pytest.raises(RuntimeError, match="GPU"):
@@ -257,6 +257,40 @@ def test_emulated_tile16_packing_matches_oracle(built_library):
     xn = (xT - f.target_shift) / f.target_scale
     xTT, logj = E.emulate(planh, net.wpack("cpu", MODE_HUTCH), table, xn, cond=f._norm_cond(cond), probe=e, mode=MODE_HUTCH)
     assert torch.isfinite(logj).all() and xTT.shape == xn.shape
+
+
+ACTIVATIONS = [torch.nn.Tanh(), torch.nn.Sigmoid(), torch.nn.ReLU(), torch.nn.LeakyReLU(0.2), torch.nn.ELU(0.7),
+               torch.nn.Softplus(), torch.nn.Softplus(beta=2.0, threshold=3.0), torch.nn.GELU(),
+               torch.nn.GELU(approximate="tanh")]
+
+
+KINKED = (torch.nn.ReLU, torch.nn.LeakyReLU, torch.nn.ELU)
+
+
+@pytest.mark.parametrize("act", ACTIVATIONS, ids=lambda a: repr(a))
+def test_activation_plumbing_matches_oracle(act, built_library):
+    """`activation=` of the reference constructors: the module maps to an FF_ACT_* plan, and the kernel
+    semantics with that activation (emulator) reproduce the oracle run with the same module."""
+    torch.manual_seed(11)
+    sm = D.ScoreModel(D.MLP(5, 2, 8, [48, 64], activation=act), D.VESDE(), no_sigma=False).eval()
+    net = sm._net()
+    plan = _native.plan_words(net.plan(MODE_EXACT))
+    assert plan[8] == net.act[0] != _native.ACT_SILU and b"_act" in built_library.ff_kernel_name(plan[6])
+    so = O.ScoreOracle(O.mlp_params_from_state_dict(sm.state_dict()), O.VE(dtype=torch.float64), no_sigma=False,
+                       dtype=torch.float64, activation=act)
+    x0, cond = torch.randn(7, 5), torch.randn(7, 2)
+    opts = {"step_size": 0.1}
+    eps = float(sm.sde.epsilon)
+    table = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, MODE_EXACT)
+    xT, dl = _emulate_score(sm, x0, table, MODE_EXACT, cond)
+    want_x, want_dl = so.solve_odes_forward(x0.double(), cond.double(), "rk4", opts, divergence="exact")
+    torch.testing.assert_close(xT, want_x, rtol=2e-5, atol=2e-5)          # fp32 time table vs float64 oracle
+    if not isinstance(act, KINKED):     # a slope that jumps at 0 makes the divergence discontinuous in the state
+        torch.testing.assert_close(dl.view(-1), want_dl.view(-1), rtol=2e-5, atol=2e-5)
+    # the flows take the activation as a class
+    f = F.ODEFlow(3, [32, 32], activation=type(act)).eval()
+    from flowfusion_amd.fused import activation_spec
+    assert f._net().act == activation_spec(type(act)())
 
 
 # ---- adaptive dopri5 driver (host logic) against the oracle's independent restatement -------------------
