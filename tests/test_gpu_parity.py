@@ -519,7 +519,7 @@ def test_activations_against_oracle(act):
         cd = None if cond is None else cond.to(DEV)
         opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 25}
         x0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cd, method="rk4", options=opts)
-        ref, _ = so32.sample_ode_from_base(base, cond, "rk4", opts)
+        ref = so32.sample_ode_from_base(base, cond, "rk4", opts)
         assert _state_err(x0, ref) < STATE_TOL, (act, units)
         xd = torch.randn(40, D)
         cdd = None if cond is None else cond[:40]
