@@ -44,6 +44,29 @@ def activation_spec(act) -> Tuple[int, float, float]:
         "ReLU, LeakyReLU, ELU, Softplus and GELU")
 
 
+def exact_trace_passes(dim: int, tile: int) -> List[Tuple[int, int]]:
+    """Split the `dim` unit tangents of an exact trace into launches [(first, count), ...].
+
+    A wavefront carries `tile` MFMA columns; a launch with n tangents per sample packs
+    floor(tile / (1 + n)) samples into them, so it costs tile / floor(tile / (1 + n)) columns per
+    sample (the value column is recomputed by every launch).  The cheapest partition is not always
+    the fewest launches: 8 dimensions on 16 columns cost 16 in one launch (9 columns, one sample per
+    wavefront) but 8 + 2 as 7 + 1.  Small dynamic programme over the partitions of `dim`."""
+    cost = [0.0] + [tile / (tile // (1 + n)) for n in range(1, tile)]
+    best = [(0.0, [])] + [None] * dim
+    for d in range(1, dim + 1):
+        cands = []
+        for n in range(1, min(d, tile - 1) + 1):
+            c, parts = best[d - n]
+            cands.append((c + cost[n] + 1e-9 * (len(parts) + 1), parts + [n]))   # ties: fewer launches
+        best[d] = min(cands, key=lambda cp: cp[0])
+    out, first = [], 0
+    for n in sorted(best[dim][1], reverse=True):
+        out.append((first, n))
+        first += n
+    return out
+
+
 class FusedNet:
     """Kernel-side view of ``Linear -> SiLU -> ... -> Linear`` with first-layer input
     ``[ time part | x | cond ]`` in any column order."""
@@ -114,16 +137,15 @@ class FusedNet:
             cond = None
         args = (f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
                 f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift), _native.plan_words(plan), mode)
-        if mode != MODE_EXACT or self.dim + 1 <= plan.tile:
+        if mode != MODE_EXACT:
             return torch.ops.flowfusion_amd.mlp_ode(*args)
-        # exact trace over more dimensions than one wavefront carries tangents for: the trace is a
-        # sum over dimensions, so integrate it in passes of (tile - 1) unit tangents and add up
-        per = plan.tile - 1
-        total = None
-        for first in range(0, self.dim, per):
-            y, dl, st = torch.ops.flowfusion_amd.mlp_ode(*args, first, min(per, self.dim - first))
+        # exact trace = sum over dimensions of unit-tangent contributions: integrate it in the
+        # cheapest set of launches (each carries at most tile - 1 tangents per sample) and add up
+        total = status = None
+        for first, count in exact_trace_passes(self.dim, plan.tile):
+            y, dl, st = torch.ops.flowfusion_amd.mlp_ode(*args, first, count)
             total = dl if total is None else total + dl
-            status = st if first == 0 else (status | st)
+            status = st if status is None else (status | st)
         return y, total, status
 
     def cached_table(self, key, device, build):
@@ -155,9 +177,7 @@ class FusedNet:
             wpack = self.wpack(device, mode)
             launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count: torch.ops.flowfusion_amd.mlp_ode_step(
                 y, cond_d, probe_d, k1, kl1, lp0, wpack, etab.to(device), words, mode, n_aux, first, count)
-        per = plan.tile - 1
-        passes = [(0, 0)] if (mode != MODE_EXACT or self.dim + 1 <= plan.tile) else \
-            [(first, min(per, self.dim - first)) for first in range(0, self.dim, per)]
+        passes = [(0, 0)] if mode != MODE_EXACT else exact_trace_passes(self.dim, plan.tile)
 
         def step(y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux):
             n = int(t_rows.numel())

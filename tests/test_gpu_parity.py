@@ -257,6 +257,33 @@ def test_exact_trace_in_several_passes():
     assert _logp_err(lp, so64.log_prob(x0.double(), None, "midpoint", o2, "exact").float()) < LOGP_TOL
 
 
+@pytest.mark.parametrize("D,units", [(8, [256, 256]), (12, [128, 128]), (16, [128, 100])])
+def test_exact_trace_partition_equals_single_launch(D, units):
+    """The exact trace is split into the cheapest set of launches (fused.exact_trace_passes), e.g. 8
+    dimensions on 16 columns as 7 + 1: same log-density as one launch carrying all unit tangents, and
+    as the oracle."""
+    from flowfusion_amd.fused import exact_trace_passes, MODE_EXACT
+    from flowfusion_amd import _native
+    sm, _, so64 = _seeded_score_model(D, 0, units, "VESDE", False, 50 + D)
+    net = sm._net()
+    plan = net.plan(MODE_EXACT)
+    passes = exact_trace_passes(D, plan.tile)
+    assert len(passes) > 1 and sum(n for _, n in passes) == D
+    x0 = torch.randn(50, D)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
+    tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), "rk4", opts, MODE_EXACT)
+    xT, dl, _ = net.integrate(x0.to(DEV), tab, MODE_EXACT)
+    rx, rdl = so64.solve_odes_forward(x0.double(), None, "rk4", opts, "exact")
+    assert _state_err(xT, rx.float()) < STATE_TOL
+    assert _logp_err(dl, rdl.view(-1).float()) < LOGP_TOL
+    if D + 1 <= plan.tile:
+        y1, dl1, _ = torch.ops.flowfusion_amd.mlp_ode(x0.to(DEV), None, None, None, net.wpack(DEV, MODE_EXACT),
+                                                      tab.to(DEV), None, None, None, None,
+                                                      _native.plan_words(plan), MODE_EXACT)
+        assert torch.equal(y1, xT)
+        assert _logp_err(dl, dl1.cpu()) < 2e-6
+
+
 def test_config4_flow_64d_5x512():
     """BASELINE config 4 shape (64-dim flow matching, MLP 5x512) on the 16x16x4 kernels: sampling
     with RK4 and fixed-step Dormand-Prince, and the Hutchinson log-density extension."""
