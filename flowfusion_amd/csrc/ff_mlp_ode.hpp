@@ -300,7 +300,11 @@ __device__ __forceinline__ void ff_stamp(unsigned long long* buf, int& n, bool o
 //                  times after the last one: the caller hangs the activation stages of finished
 //                  blocks on these slots
 //   last(acc)      called once the last block's accumulator is complete
-template <int TILE, int RING, int KR, int NOB, bool WRAP, class PreFn, class SlotFn, class LastFn, class DbgFn>
+//   LAST_PHYS      physical tiles of the last block that carry rows anybody reads (the output layer of a
+//                  <= 16-dimensional state on the 16-row tile needs one of two): the MFMAs of the others
+//                  are not issued and their accumulators read as zero
+template <int TILE, int RING, int KR, int NOB, bool WRAP, int LAST_PHYS = Tile<TILE>::PHYS, class PreFn, class SlotFn,
+          class LastFn, class DbgFn>
 __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS], const Stream& ws, int lane16,
                                           int sbyte, const float (&B)[KR], PreFn&& pre_block, SlotFn&& slot_fn,
                                           LastFn&& last, DbgFn&& dbg)
@@ -323,7 +327,9 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
                 constexpr int q = decltype(qq)::value;
                 static_for<T::PHYS>([&](auto pp) {
                     constexpr int p = decltype(pp)::value;
-                    if constexpr (g == 0 && q == 0)
+                    if constexpr (ob == NOB - 1 && p >= LAST_PHYS) {
+                        if constexpr (g == 0 && q == 0) acc[ob].v[p] = T::zero();
+                    } else if constexpr (g == 0 && q == 0)
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], T::zero());
                     else
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], acc[ob].v[p]);
@@ -628,7 +634,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         }
         // ---- output layer ----------------------------------------------------------------
         float net[NOB_OUT * RB];
-        run_layer<TILE, RING, KH, NOB_OUT, true>(
+        constexpr int OUT_LAST_PHYS = (DREGS * T::NQ - (NOB_OUT - 1) * 32 + TILE - 1) / TILE;   // tiles with state rows
+        run_layer<TILE, RING, KH, NOB_OUT, true, (OUT_LAST_PHYS < T::PHYS ? OUT_LAST_PHYS : T::PHYS)>(
             ring, ws, lane16, out_sbyte, P,
             [&](auto ob) {
                 constexpr int o = decltype(ob)::value;

@@ -9,7 +9,7 @@ cat > $T/table.cpp <<EOT
 #include "ff_registry.h"
 namespace ff {
 int launch_mlp_ode_m16_h256_d4_c0_t0_w2(const KernelArgs*, unsigned, unsigned, hipStream_t);
-const KernelEntry g_kernels[] = { {16, 256, 4, 0, 0, launch_mlp_ode_m16_h256_d4_c0_t0_w2, "mlp_ode_m16_h256_d4_c0_t0_w2"} };
+const KernelEntry g_kernels[] = { {16, 256, 4, 0, 0, 0, launch_mlp_ode_m16_h256_d4_c0_t0_w2, "mlp_ode_m16_h256_d4_c0_t0_w2"} };
 const int g_n_kernels = 1;
 }
 EOT
