@@ -249,6 +249,13 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
         }
         return;
     }
+#ifdef FF_DEBUG_LINEAR_ACT      // timing experiment only: identity activation (wrong results)
+    if constexpr (STAGE == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = g.pre[i];
+    }
+    return;
+#endif
     // scalar code on purpose: packed f32 VALU (v_pk_*) issued beside MFMAs costs more than it saves
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -259,15 +266,17 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
         } else if constexpr (STAGE == 2) {
             g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
         } else if constexpr (STAGE == 3) {
-            g.h[i] = g.pre[i] * g.r[i];
             if constexpr (TANGENTS) {
-                const float d = __builtin_fmaf(g.h[i], 1.0f - g.r[i], g.r[i]);
+                // silu'(a) = s + a s (1 - s) = s (1 + a (1 - s)),  s = sigmoid(a): two fmas
+                const float w = __builtin_fmaf(-g.pre[i], g.r[i], g.pre[i]);
+                const float d = __builtin_fmaf(g.r[i], w, g.r[i]);
                 g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d));
             } else {
-                dst[i] = g.h[i];
+                dst[i] = g.pre[i] * g.r[i];
             }
         } else {
-            if constexpr (TANGENTS) dst[i] = is_tangent ? __builtin_bit_cast(float, g.dv[i]) * g.pre[i] : g.h[i];
+            // value columns: a * s;  tangent columns: a' * silu'(a of the value column)
+            if constexpr (TANGENTS) dst[i] = g.pre[i] * (is_tangent ? __builtin_bit_cast(float, g.dv[i]) : g.r[i]);
         }
     }
 }
@@ -430,6 +439,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         sample = wave * TILE + col;
     }
     if (sample >= args.batch) { sample = args.batch - 1; col_live = false; }
+    const int q16b = (TANGENTS && is_tangent) ? 0x7ffffff0 : q16;     // bias offset: out of range = zero
 
     // ---- load state (value columns) / tangent vectors -----------------------------------
     float x[DREGS];
@@ -561,10 +571,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         float pend[RB];
         BiasBlk<TILE> bias[2];
         ActGroup ag[12];         // in-flight groups: [0,4) parked block of the previous layer, 4 + id % 8 own blocks
-        auto bias1 = [&](const BiasBlk<TILE>& b, int r) {
-            const float v = b.reg(r);
-            return TANGENTS ? (is_tangent ? 0.f : v) : v;
-        };
+        // tangent columns take no bias: their lanes fetch it through an out-of-range buffer offset, which
+        // reads as zero (no select in the activation path)
+        auto bias1 = [&](const BiasBlk<TILE>& b, int r) { return b.reg(r); };
         // stages of the previous layer's parked block: group gi starts at slot gi*(16*PHYS/GPB)
         auto prev_slot = [&](auto mm) {
             constexpr int M = decltype(mm)::value;
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 ring, ws, lane16, 0, y,
                 [&](auto ob) {
                     constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias<TILE>(ts, q16, row_byte + 128 + o * 128);
+                    bias[o & 1] = load_bias<TILE>(ts, q16b, row_byte + 128 + o * 128);
                 },
                 [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) { own_slot(G1{}, mm, acc); }, park_last, dbg);
         }
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 ring, ws, lane16, sbyte, P,
                 [&](auto ob) {
                     constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias<TILE>(ws, q16, bbyte + o * 128);
+                    bias[o & 1] = load_bias<TILE>(ws, q16b, bbyte + o * 128);
                 },
                 [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) {
                     prev_slot(mm);
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             ring, ws, lane16, out_sbyte, P,
             [&](auto ob) {
                 constexpr int o = decltype(ob)::value;
-                bias[o & 1] = load_bias<TILE>(ws, q16, out_bias_byte + o * 128);
+                bias[o & 1] = load_bias<TILE>(ws, q16b, out_bias_byte + o * 128);
             },
             [&](auto mm, const BlockAcc<TILE> (&acc)[NOB_OUT]) {
                 prev_slot(mm);
