@@ -121,6 +121,22 @@ __device__ __forceinline__ BiasBlk<TILE> load_bias(const Stream& s, int q16, int
     return b;
 }
 
+// A bias block as the initial value of the block's accumulator tile(s) (same register order).
+template <int TILE>
+__device__ __forceinline__ BlockAcc<TILE> load_bias_acc(const Stream& s, int q16, int byte_off)
+{
+    const BiasBlk<TILE> b = load_bias<TILE>(s, q16, byte_off);
+    BlockAcc<TILE> a;
+    if constexpr (TILE == 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.v[0][r] = b.reg(r);
+    } else {
+#pragma unroll
+        for (int j = 0; j < Tile<TILE>::PHYS; ++j) a.v[j] = b.v[j];
+    }
+    return a;
+}
+
 // Activation of 4 registers, cut into stages that are issued one MFMA apart, so that no
 // instruction waits on the one just before it (a lone SiLU chain  add -> mul -> exp -> add -> rcp ->
 // mul  costs ~100 cycles of back-to-back latency; the in-order wavefront would hold the next
@@ -312,16 +328,18 @@ __device__ __forceinline__ void ff_stamp(unsigned long long* buf, int& n, bool o
 //   LAST_PHYS      physical tiles of the last block that carry rows anybody reads (the output layer of a
 //                  <= 16-dimensional state on the 16-row tile needs one of two): the MFMAs of the others
 //                  are not issued and their accumulators read as zero
-template <int TILE, int RING, int KR, int NOB, bool WRAP, int LAST_PHYS = Tile<TILE>::PHYS, class PreFn, class SlotFn,
-          class LastFn, class DbgFn>
+//   acc            the layer's accumulators.  ZERO_INIT: they start from zero (the first MFMA of a block takes a
+//                  zero C operand); otherwise they come in holding the layer's bias, which the MFMA chain then
+//                  adds for free (the caller loads the next layer's bias into a block once it has been consumed)
+template <int TILE, int RING, int KR, int NOB, bool WRAP, bool ZERO_INIT, int LAST_PHYS = Tile<TILE>::PHYS, class PreFn,
+          class SlotFn, class LastFn, class DbgFn>
 __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS], const Stream& ws, int lane16,
-                                          int sbyte, const float (&B)[KR], PreFn&& pre_block, SlotFn&& slot_fn,
-                                          LastFn&& last, DbgFn&& dbg)
+                                          int sbyte, const float (&B)[KR], BlockAcc<TILE> (&acc)[NOB],
+                                          PreFn&& pre_block, SlotFn&& slot_fn, LastFn&& last, DbgFn&& dbg)
 {
     typedef Tile<TILE> T;
     constexpr LayerGeom L = layer_geom(KR, NOB, T::RB / 4);
     constexpr int CB = 1024 * T::PHYS;              // bytes per chunk
-    BlockAcc<TILE> acc[NOB];
     dbg();
     static_for<L.CPAD>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -337,8 +355,8 @@ __device__ __forceinline__ void run_layer(f32x4 (&ring)[RING][Tile<TILE>::PHYS],
                 static_for<T::PHYS>([&](auto pp) {
                     constexpr int p = decltype(pp)::value;
                     if constexpr (ob == NOB - 1 && p >= LAST_PHYS) {
-                        if constexpr (g == 0 && q == 0) acc[ob].v[p] = T::zero();
-                    } else if constexpr (g == 0 && q == 0)
+                        if constexpr (g == 0 && q == 0 && ZERO_INIT) acc[ob].v[p] = T::zero();
+                    } else if constexpr (g == 0 && q == 0 && ZERO_INIT)
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], T::zero());
                     else
                         acc[ob].v[p] = T::mfma(ring[slot][p][q], B[4 * g + q], acc[ob].v[p]);
@@ -521,6 +539,13 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         for (int p = 0; p < T::PHYS; ++p) ring[i][p] = sload(ws, lane16, i * CB + p * 1024);
 
     float P[KH];
+    // Accumulators of the hidden layers.  They always hold the bias of the layer about to run: a block is
+    // refilled with the next layer's bias (straight from the bias stream, in accumulator order) as soon as its
+    // pre-activations have been consumed, so the MFMA chain adds the bias and the activation path does not.
+    // Tangent lanes fetch through an out-of-range offset (q16b) and start from zero.
+    BlockAcc<TILE> hacc[NB];
+#pragma unroll
+    for (int o = 0; o < NB; ++o) hacc[o] = load_bias_acc<TILE>(ts, q16b, 128 + o * 128);
 #ifdef FF_DEBUG_STAMPS
     int stamp_n = 0;
     const bool stamp_on = (blockIdx.x == 0 && threadIdx.x == 0 && args.debug_stamps != nullptr);
@@ -565,14 +590,13 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #else
         auto dbg = []() {};
 #endif
-        // `pend` = pre-activations (accumulator + bias) of the previous layer's last block; they
+        // `pend` = pre-activations of the previous layer's last block; they
         // are activated into P[(NB-1)*RB ..] behind the first MFMAs of the next layer, whose
         // phase A does not read the last k-block.
         float pend[RB];
         BiasBlk<TILE> bias[2];
         ActGroup ag[12];         // in-flight groups: [0,4) parked block of the previous layer, 4 + id % 8 own blocks
-        // tangent columns take no bias: their lanes fetch it through an out-of-range buffer offset, which
-        // reads as zero (no select in the activation path)
+        // (output layer only; tangent lanes read zeros through q16b)
         auto bias1 = [&](const BiasBlk<TILE>& b, int r) { return b.reg(r); };
         // stages of the previous layer's parked block: group gi starts at slot gi*(16*PHYS/GPB)
         auto prev_slot = [&](auto mm) {
@@ -603,49 +627,59 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                     if constexpr (k == 0) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            ag[4 + id % 8].pre[i] = acc[blk].reg(4 * gi + i) + bias1(bias[blk & 1], 4 * gi + i);
+                            ag[4 + id % 8].pre[i] = acc[blk].reg(4 * gi + i);
                     }
                     act_stage<TANGENTS, GENERIC_ACT, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
                 }
             });
         };
-        auto park_last = [&](const BlockAcc<TILE>& acc) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r) pend[r] = acc.reg(r) + bias1(bias[(NB - 1) & 1], r);
+        // Refill schedule: at the first phase-B chunk of block ob, block ob-2 has been consumed (its groups
+        // start their stages while block ob-1 runs); the last two blocks follow at the end of the layer, the
+        // last one after its pre-activations have been parked.
+        auto refill = [&](const Stream& st, int byte, auto ob) {
+            constexpr int o = decltype(ob)::value;
+            if constexpr (o >= 2) hacc[o - 2] = load_bias_acc<TILE>(st, q16b, byte + (o - 2) * 128);
         };
-        // ---- layer 1: [x | cond] -> H, bias c1_e ---------------------------------------
+        auto park_and_refill = [&](const Stream& st, int byte, const BlockAcc<TILE>& acc) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) pend[r] = acc.reg(r);
+            if constexpr (NB >= 2) hacc[NB - 2] = load_bias_acc<TILE>(st, q16b, byte + (NB - 2) * 128);
+            hacc[NB - 1] = load_bias_acc<TILE>(st, q16b, byte + (NB - 1) * 128);
+        };
+        // ---- layer 1: [x | cond] -> H, bias c1_e (already in hacc) ------------------------
         {
             using G1 = GeomTag<TILE, K1, NB>;
-            run_layer<TILE, RING, K1, NB, false>(
-                ring, ws, lane16, 0, y,
-                [&](auto ob) {
-                    constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias<TILE>(ts, q16b, row_byte + 128 + o * 128);
-                },
-                [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) { own_slot(G1{}, mm, acc); }, park_last, dbg);
+            const int nbyte = (int)(L.bias_off_hid(0) * 4);          // next: first hidden->hidden layer
+            run_layer<TILE, RING, K1, NB, false, false>(
+                ring, ws, lane16, 0, y, hacc, [&](auto ob) { refill(ws, nbyte, ob); },
+                [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) { own_slot(G1{}, mm, acc); },
+                [&](const BlockAcc<TILE>& acc) { park_and_refill(ws, nbyte, acc); }, dbg);
         }
         // ---- hidden -> hidden ------------------------------------------------------------
         for (int l = 0; l < args.n_hidden - 1; ++l) {
             using GH = GeomTag<TILE, KH, NB>;
             const int sbyte = L.chunk_off_hid(l) * CB;
-            const int bbyte = (int)(L.bias_off_hid(l) * 4);
-            run_layer<TILE, RING, KH, NB, false>(
-                ring, ws, lane16, sbyte, P,
-                [&](auto ob) {
-                    constexpr int o = decltype(ob)::value;
-                    bias[o & 1] = load_bias<TILE>(ws, q16b, bbyte + o * 128);
-                },
+            // next layer's bias; after the last hidden layer nothing reads hacc before the output layer
+            // replaces it with the next row's c1, so whatever this fetches then is ignored
+            const int nbyte = (int)(L.bias_off_hid(l + 1) * 4);
+            run_layer<TILE, RING, KH, NB, false, false>(
+                ring, ws, lane16, sbyte, P, hacc, [&](auto ob) { refill(ws, nbyte, ob); },
                 [&](auto mm, const BlockAcc<TILE> (&acc)[NB]) {
                     prev_slot(mm);
                     own_slot(GH{}, mm, acc);
                 },
-                park_last, dbg);
+                [&](const BlockAcc<TILE>& acc) { park_and_refill(ws, nbyte, acc); }, dbg);
         }
         // ---- output layer ----------------------------------------------------------------
         float net[NOB_OUT * RB];
+        // the hidden accumulators are idle from here to the next evaluation's first layer: fetch its c1 now
+        // (a row past the table reads as zeros)
+#pragma unroll
+        for (int o = 0; o < NB; ++o) hacc[o] = load_bias_acc<TILE>(ts, q16b, row_byte + args.etab_stride * 4 + 128 + o * 128);
+        BlockAcc<TILE> oacc[NOB_OUT];
         constexpr int OUT_LAST_PHYS = (DREGS * T::NQ - (NOB_OUT - 1) * 32 + TILE - 1) / TILE;   // tiles with state rows
-        run_layer<TILE, RING, KH, NOB_OUT, true, (OUT_LAST_PHYS < T::PHYS ? OUT_LAST_PHYS : T::PHYS)>(
-            ring, ws, lane16, out_sbyte, P,
+        run_layer<TILE, RING, KH, NOB_OUT, true, true, (OUT_LAST_PHYS < T::PHYS ? OUT_LAST_PHYS : T::PHYS)>(
+            ring, ws, lane16, out_sbyte, P, oacc,
             [&](auto ob) {
                 constexpr int o = decltype(ob)::value;
                 bias[o & 1] = load_bias<TILE>(ws, q16b, out_bias_byte + o * 128);
