@@ -72,7 +72,9 @@ class OdeArgs(ctypes.Structure):
         ("aux_out", ctypes.c_void_p * 4),
         ("aux_lp_out", ctypes.c_void_p * 4),
         ("n_aux", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("rng_noise_base", ctypes.c_int32),
+        ("rng_seed", ctypes.c_uint64),
+        ("rng_sample_offset", ctypes.c_int64),
     ]
 
 
@@ -192,9 +194,12 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
             noise: Optional[torch.Tensor], wpack: torch.Tensor, etab: torch.Tensor,
             in_shift: Optional[torch.Tensor], in_scale: Optional[torch.Tensor],
             out_scale: Optional[torch.Tensor], out_shift: Optional[torch.Tensor],
-            plan: List[int], mode: int, tangent_first: int = 0, tangent_count: int = 0
+            plan: List[int], mode: int, tangent_first: int = 0, tangent_count: int = 0,
+            rng_seed: int = 0, rng_sample_offset: int = 0, rng_noise_base: int = 0
             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Fused integration on the GPU: returns (final state [B,D], integrated divergence [B], status[1])."""
+    """Fused integration on the GPU: returns (final state [B,D], integrated divergence [B], status[1]).
+    With `noise=None`, rows flagged FF_ROW_NOISE draw their normals in the kernel (Philox4x32-10 keyed by
+    `rng_seed` and the global sample index `rng_sample_offset + row`; see ff_ode_args)."""
     if not x.is_cuda:
         raise RuntimeError("flowfusion_amd::mlp_ode needs tensors on the GPU (there is no CPU path)")
     dev = x.device
@@ -227,6 +232,9 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
     a.mode = mode
     a.tangent_first = tangent_first
     a.tangent_count = tangent_count
+    a.rng_seed = rng_seed & 0xFFFFFFFFFFFFFFFF
+    a.rng_sample_offset = rng_sample_offset
+    a.rng_noise_base = rng_noise_base
     if cond is not None and tuple(cond.shape) != (B, p.cond_dim):
         raise RuntimeError(f"cond has shape {tuple(cond.shape)}, expected {(B, p.cond_dim)}")
     if probe is not None and tuple(probe.shape) != (B, D):
@@ -243,7 +251,7 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
 
 @mlp_ode.register_fake
 def _(x, cond, probe, noise, wpack, etab, in_shift, in_scale, out_scale, out_shift, plan, mode,
-      tangent_first=0, tangent_count=0):
+      tangent_first=0, tangent_count=0, rng_seed=0, rng_sample_offset=0, rng_noise_base=0):
     B = x.shape[0]
     return (torch.empty_like(x), x.new_empty(B if mode != MODE_STATE else 0),
             torch.empty(1, dtype=torch.int32, device=x.device))

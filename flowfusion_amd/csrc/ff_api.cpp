@@ -214,6 +214,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
     ka.k1_in = a->k1_in; ka.kl1_in = a->kl1_in; ka.dlogp_in = a->dlogp_in; ka.n_aux = a->n_aux;
     for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
+    ka.rng_seed = a->rng_seed; ka.rng_sample_offset = a->rng_sample_offset; ka.rng_noise_base = a->rng_noise_base;
     ka.act_kind = plan->activation; ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);

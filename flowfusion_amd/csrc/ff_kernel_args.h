@@ -40,6 +40,10 @@ struct KernelArgs {
     float* aux_out[kAux];
     float* aux_lp_out[kAux];
     int n_aux;
+    // in-kernel noise (used when `noise` is NULL): Philox key, global index of row 0, noise index of row 0
+    unsigned long long rng_seed;
+    long long rng_sample_offset;
+    int rng_noise_base;
     int act_kind;        // FF_ACT_* (read by the run-time-activation instantiations only)
     float act_p0, act_p1;
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product

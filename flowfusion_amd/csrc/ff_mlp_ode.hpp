@@ -121,6 +121,30 @@ __device__ __forceinline__ BiasBlk<TILE> load_bias(const Stream& s, int q16, int
     return b;
 }
 
+// Counter-based normal deviates for the Euler-Maruyama rows (include/flowfusion_amd.h, "In-kernel noise"):
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the caller's seed, counter = (global sample index lo/hi,
+// noise index, dimension / 4); its four words make four normals by two Box-Muller pairs.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1)
+{
+    const float u1 = __builtin_fmaf((float)(a >> 8), 0x1p-24f, 0x1p-25f);        // (0, 1)
+    const float u2 = (float)(b >> 8) * 0x1p-24f;                                   // [0, 1): a turn
+    const float rad = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    z0 = rad * __builtin_amdgcn_cosf(u2);                                          // v_cos/v_sin take turns
+    z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
 // A bias block as the initial value of the block's accumulator tile(s) (same register order).
 template <int TILE>
 __device__ __forceinline__ BlockAcc<TILE> load_bias_acc(const Stream& s, int q16, int byte_off)
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 
         // noise for this row (requested early, consumed after the network)
         float nz[DREGS];
-        if (flags & 2u) {
+        if ((flags & 2u) && args.noise) {
             const float* np = args.noise + (size_t)hdr->noise_idx * args.noise_stride + sample * D;
 #pragma unroll
             for (int r = 0; r < DREGS; ++r) {
@@ -742,6 +766,19 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             }
         }
         if (flags & 2u) {
+            if constexpr (!TANGENTS) {
+                if (!args.noise) {      // in-kernel noise: registers 4j..4j+3 of a lane are dimensions 4*blk..4*blk+3
+                    const unsigned long long gs = (unsigned long long)(sample + args.rng_sample_offset);
+#pragma unroll
+                    for (int j = 0; j < R4; ++j) {
+                        uint32_t c[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(hdr->noise_idx + args.rng_noise_base),
+                                         (uint32_t)(feat_of_reg(TILE, 4 * j, qd) >> 2)};
+                        philox4x32_10(c, (uint32_t)args.rng_seed, (uint32_t)(args.rng_seed >> 32));
+                        box_muller(c[0], c[1], nz[4 * j], nz[4 * j + 1]);
+                        box_muller(c[2], c[3], nz[4 * j + 2], nz[4 * j + 3]);
+                    }
+                }
+            }
             const float gn = hdr->gn;
 #pragma unroll
             for (int r = 0; r < DREGS; ++r) x[r] = __builtin_fmaf(gn, nz[r], x[r]);

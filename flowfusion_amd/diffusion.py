@@ -302,20 +302,34 @@ class ScoreModel(nn.Module):
         return tuple(vals) + (m.W.data_ptr(), m.W._version)
 
     @torch.no_grad()
-    def sample_sde(self, shape, conditional=None, steps=100):
+    def sample_sde(self, shape, conditional=None, steps=100, *, noise="torch", seed=None, sample_offset=0):
         """Euler-Maruyama sampling of the reverse SDE; returns the last *mean* state, like the
-        reference (diffusion.py:510-563).  Random numbers are drawn exactly as the reference draws
-        them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
-        ``torch.manual_seed`` reproduces the reference's stream on that device."""
+        reference (diffusion.py:510-563).  By default random numbers are drawn exactly as the reference
+        draws them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
+        ``torch.manual_seed`` reproduces the reference's stream on that device.
+
+        Extension: ``noise="philox"`` draws the per-step normals inside the kernel (counter-based, keyed by
+        ``seed`` and the global sample index ``sample_offset + row``; include/flowfusion_amd.h): no noise
+        buffers, no random-number kernels, and the result for a sample does not depend on how the batch is
+        split over launches or GPUs (``flowfusion_amd.distributed.sample_sde_sharded``).  ``seed=None``
+        takes one from torch's default generator, so ``torch.manual_seed`` still fixes the run."""
         batch, *dims = shape
         dev = next(self.model.parameters()).device
         x = self.sde.prior(dims).sample([batch]).to(dev)
-        return self._sample_sde_from(x, lambda like: torch.randn_like(like), conditional, steps)
+        if noise == "torch":
+            return self._sample_sde_from(x, lambda like: torch.randn_like(like), conditional, steps)
+        if noise != "philox":
+            raise ValueError(f"noise={noise!r}: expected 'torch' or 'philox'")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return self._sample_sde_from(x, None, conditional, steps, rng=(int(seed), int(sample_offset)))
 
     @torch.no_grad()
-    def _sample_sde_from(self, x, draw, conditional=None, steps=100):
+    def _sample_sde_from(self, x, draw, conditional=None, steps=100, rng=None):
         """The Euler-Maruyama loop proper: ``x`` is the prior draw, ``draw(like)`` supplies the i-th
-        standard-normal slab (tests inject the reference's captured stream here)."""
+        standard-normal slab (tests inject the reference's captured stream here); with
+        ``rng = (seed, global index of row 0)`` the kernel draws the normals itself and the whole loop is one
+        launch."""
         net = self._net()
         if x.dim() != 2:
             raise NotImplementedError("sample_sde: only [batch, dim] states are supported")
@@ -335,6 +349,14 @@ class ScoreModel(nn.Module):
         cout[:, 0] = dt                               # x_mean = x + f dt  (:557)
         zeros8 = torch.zeros(n, 8)
         slot = torch.zeros(n, dtype=torch.int32)
+        if rng is not None:
+            full = solvers.EvalPlan(t_eval=ts, sign=1.0, slot=slot, flags=flags, cin=zeros8, cout=cout, n_steps=n)
+            table = solvers.build_table(full, a, b, c1, net.width(MODE_STATE), gn=gn, noise_idx=torch.arange(n)).to(dev)
+            x, _, status = net.integrate(x, table, MODE_STATE, cond=conditional,
+                                         rng=(rng[0] & 0x7FFFFFFFFFFFFFFF, rng[1], 0))
+            if int(status.item()) & 1:
+                print("Diffusion is not stable, NaN were produced. Stopped sampling.")
+            return x
         # Noise slabs are drawn per step, in order, chunked over steps to bound memory.  The draws
         # of chunk c+1 are enqueued on a side stream while the kernel integrates chunk c (two
         # buffers), so the random-number kernels stay off the critical path; the host-side generator

@@ -63,3 +63,27 @@ def run_sharded(fn: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch
     if isinstance(local, (tuple, list)):
         return type(local)(gather_rows(t, n, group) if torch.is_tensor(t) else t for t in local)
     return gather_rows(local, n, group)
+
+
+def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] = None, steps: int = 100,
+                       seed: int = 0, group=None, gather: bool = True):
+    """Euler-Maruyama sampling (``ScoreModel.sample_sde``) of a [B, dim] batch over all ranks, with the
+    same result for any number of ranks: every rank draws the prior of the whole batch from the same
+    seeded generator and keeps its rows, and the per-step noise is the kernel's counter-based stream
+    keyed by ``seed`` and the GLOBAL row index (``noise="philox"``).  One all-gather at the end."""
+    batch, *dims = shape
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(batch, world, rank)
+    dev = next(score_model.model.parameters()).device
+    gen = torch.Generator(device=dev).manual_seed(int(seed))
+    # the prior is Normal(0, scale) (diffusion.py:1003, 1093): draw unit normals for the whole batch from the
+    # seeded generator (one pass, the same numbers on every rank) and scale them the way the prior would
+    unit = torch.randn((batch, *dims), generator=gen, device=dev)
+    scale = score_model.sde.prior(dims).scale
+    x = (unit[lo:hi] * scale.to(dev)).contiguous()
+    cond = None if conditional is None else conditional[lo:hi].contiguous()
+    local = score_model._sample_sde_from(x, None, cond, steps, rng=(int(seed), lo))
+    if not gather:
+        return local, (lo, hi)
+    return gather_rows(local, batch, group) if world > 1 else local

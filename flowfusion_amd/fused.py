@@ -116,8 +116,11 @@ class FusedNet:
     def integrate(self, x: torch.Tensor, etab: torch.Tensor, mode: int = MODE_STATE,
                   cond: Optional[torch.Tensor] = None, probe: Optional[torch.Tensor] = None,
                   noise: Optional[torch.Tensor] = None,
-                  in_shift=None, in_scale=None, out_scale=None, out_shift=None):
-        """Run the fused integration.  Returns (y_final [B,D], dlogp [B] or empty, status [1])."""
+                  in_shift=None, in_scale=None, out_scale=None, out_shift=None,
+                  rng: Optional[Tuple[int, int, int]] = None):
+        """Run the fused integration.  Returns (y_final [B,D], dlogp [B] or empty, status [1]).
+        ``rng = (seed, global index of row 0, noise index of table row 0)`` selects in-kernel noise for
+        tables with noise rows (instead of a ``noise`` buffer)."""
         if not x.is_cuda:
             raise RuntimeError(
                 "flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
@@ -137,6 +140,10 @@ class FusedNet:
             cond = None
         args = (f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
                 f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift), _native.plan_words(plan), mode)
+        if rng is not None:
+            if mode != MODE_STATE or noise is not None:
+                raise ValueError("in-kernel noise applies to state-only integration without a noise buffer")
+            return torch.ops.flowfusion_amd.mlp_ode(*args, 0, 0, int(rng[0]), int(rng[1]), int(rng[2]))
         if mode != MODE_EXACT:
             return torch.ops.flowfusion_amd.mlp_ode(*args)
         # exact trace = sum over dimensions of unit-tangent contributions: integrate it in the

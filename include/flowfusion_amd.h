@@ -103,7 +103,8 @@ typedef struct ff_ode_args {
     const float* cond;       /* [batch, cond_dim] or NULL                                  */
     const float* probe;      /* [batch, dim]  Hutchinson probe e (FF_MODE_HUTCH) or NULL   */
     float*       dlogp_out;  /* [batch]       integrated divergence (modes 1,2) or NULL    */
-    const float* noise;      /* [n_noise, batch, dim] standard normals (EM) or NULL        */
+    const float* noise;      /* [n_noise, batch, dim] standard normals (EM); NULL = in-kernel
+                                noise (rng_* below) if the table has FF_ROW_NOISE rows      */
     const float* wpack;      /* packed weights, ff_mlp_wpack_floats() floats               */
     const float* etab;       /* [n_evals, FF_ROW_HDR + width] evaluation rows              */
     const float* in_shift;   /* [dim] or NULL: y0 = (x_in - in_shift) / in_scale           */
@@ -136,7 +137,17 @@ typedef struct ff_ode_args {
     float*       aux_out[FF_MAX_AUX];     /* [batch, dim] each, or NULL                            */
     float*       aux_lp_out[FF_MAX_AUX];  /* [batch] each, or NULL                                 */
     int32_t      n_aux;
-    int32_t      reserved;
+    int32_t      rng_noise_base;  /* added to the rows' noise_index in the Philox counter          */
+    /* --- in-kernel noise (FF_MODE_STATE; used by FF_ROW_NOISE rows when `noise` is NULL) ---------
+     * The standard normal of (global sample g = rng_sample_offset + row, noise index n =
+     * rng_noise_base + the row header's noise_index, dimension d) is word d%4 of
+     *     Philox4x32-10( counter = (g lo, g hi, n, d/4), key = (rng_seed lo, rng_seed hi) )
+     * turned into normals pairwise by Box-Muller: u1 = ((w_a >> 8) + 0.5) 2^-24, u2 = (w_b >> 8) 2^-24,
+     * z_a = sqrt(-2 ln u1) cos(2 pi u2), z_b = sqrt(-2 ln u1) sin(2 pi u2), (a, b) = (0, 1), (2, 3).
+     * Keyed by the GLOBAL sample index, the stream of a sample does not depend on how a batch is cut
+     * into launches or shards: 1-, 2-, 4- and 8-GPU runs of one seed give the same samples. */
+    uint64_t     rng_seed;
+    int64_t      rng_sample_offset;
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

@@ -143,9 +143,15 @@ def _tangents(plan, mode, probe, B, first=0, count=0):
 
 
 def emulate(plan, wpack, etab, x_in, cond=None, probe=None, noise=None, mode=0,
-            in_shift=None, in_scale=None, out_scale=None, out_shift=None):
-    """Returns (x_out [B,D], dlogp [B]) in float64."""
+            in_shift=None, in_scale=None, out_scale=None, out_shift=None, rng=None):
+    """Returns (x_out [B,D], dlogp [B]) in float64.  ``rng = (seed, sample_offset, noise_base)`` stands for
+    the in-kernel noise (tests/_philox.py) when no noise buffer is given."""
     D = plan[0]
+    if rng is not None and noise is None:
+        from tests._philox import normals
+        ints = etab.contiguous().view(torch.int32)
+        n_idx = int(ints[:, 5].max()) + 1
+        noise = torch.from_numpy(normals(rng[0], rng[1], x_in.shape[0], D, [rng[2] + i for i in range(n_idx)]))
     x = x_in.double()
     if in_shift is not None:
         x = x - in_shift.double()

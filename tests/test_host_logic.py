@@ -359,3 +359,65 @@ def test_adaptive_nan_error_estimate_raises_like_torchdiffeq(built_library):
     solver = adaptive.Dopri5(step, False, 1e-5, 1e-5, None)
     with pytest.raises(RuntimeError, match="underflow in dt"):
         solver.integrate(-1.0, -0.001, torch.randn(7, 6), None)
+
+
+# ---- in-kernel noise: the published generator and the header's mapping -----------------------------------
+def test_philox_known_answers_and_normals():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors) pin the restatement the GPU tests compare the
+    kernel with; the Box-Muller mapping gives standard normals."""
+    import numpy as np
+    from tests._philox import normals, philox4x32_10
+    kat = [([0, 0, 0, 0], (0, 0), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0),
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert [int(v) for v in got] == want
+    z = normals(seed=2024, sample_offset=0, batch=100000, dim=6, noise_indices=[0, 1, 2])
+    assert z.shape == (3, 100000, 6) and np.isfinite(z).all()
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3 and abs((z ** 4).mean() - 3) < 5e-2
+    # keyed by the global row index: a shard sees exactly its rows of the whole-batch stream
+    part = normals(2024, 4000, 1000, 6, [1])
+    assert np.array_equal(part[0], z[1, 4000:5000])
+    # distinct streams per noise index, dimension and seed
+    assert abs(np.corrcoef(z[0, :, 0], z[1, :, 0])[0, 1]) < 0.02 and abs(np.corrcoef(z[0, :, 0], z[0, :, 1])[0, 1]) < 0.02
+    assert not np.array_equal(normals(2025, 0, 10, 6, [0]), z[:1, :10])
+
+
+def test_emulated_euler_maruyama_with_philox_noise(built_library):
+    """Host plumbing of noise="philox": the table of a whole Euler-Maruyama run (one launch) through the kernel
+    semantics with the restated generator equals the oracle's loop fed with the same normals."""
+    import numpy as np
+    from tests._philox import normals
+    torch.manual_seed(3)
+    sm = D.ScoreModel(D.MLP(6, 2, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+    so = O.ScoreOracle(O.mlp_params_from_state_dict(sm.state_dict()), O.VE(dtype=torch.float64), no_sigma=False,
+                       dtype=torch.float64)
+    B, steps, seed, off = 9, 12, 77, 1000
+    x = torch.randn(B, 6) * 10
+    cond = torch.randn(B, 2)
+    captured = {}
+
+    real = sm._net
+    net = real()
+
+    class _Net:
+        def __getattr__(self, k):
+            return getattr(net, k)
+
+        def integrate(self, x, table, mode, cond=None, noise=None, rng=None, **kw):
+            captured["rng"] = rng
+            plan = _native.plan_words(net.plan(mode))
+            y, _ = E.emulate(plan, net.wpack("cpu", mode), table, x, cond=cond, mode=mode, rng=rng)
+            return y.float(), None, torch.zeros(1, dtype=torch.int32)
+
+    sm._net = lambda: _Net()
+    try:
+        got = sm._sample_sde_from(x, None, cond, steps, rng=(seed, off))
+    finally:
+        sm._net = real
+    assert captured["rng"] == (seed, off, 0)
+    z = torch.from_numpy(normals(seed, off, B, 6, list(range(steps)))).double()
+    want = so.sample_sde(x.double(), [z[i] for i in range(steps)], cond.double(), steps=steps)
+    torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
