@@ -30,3 +30,8 @@ t0=time.time(); x = sm.sample_sde((B, 32), conditional=cond, steps=1000); torch.
 t0=time.time(); x = sm.sample_sde((B, 32), conditional=cond, steps=1000); torch.cuda.synchronize(); dt=time.time()-t0
 mac = 48*256 + 3*256*256 + 256*32
 print(f"C5 EM 1000 steps B={B}: {dt*1e3:.1f} ms  {B/dt:.0f} samples/s  {2.0*mac*1000*B/dt/1e12:.1f} TFLOP/s (wall, incl. torch noise generation) finite={torch.isfinite(x).all().item()}", flush=True)
+for B in (1 << 17, 1 << 20):
+    cond = torch.randn(B, 8, device=dev)
+    x = sm.sample_sde((B, 32), conditional=cond, steps=1000, noise="philox", seed=1); torch.cuda.synchronize()
+    t0=time.time(); x = sm.sample_sde((B, 32), conditional=cond, steps=1000, noise="philox", seed=1); torch.cuda.synchronize(); dt=time.time()-t0
+    print(f"C5 EM 1000 steps B={B} in-kernel Philox noise: {dt*1e3:.1f} ms  {B/dt:.0f} samples/s  {2.0*mac*1000*B/dt/1e12:.1f} TFLOP/s (wall) finite={torch.isfinite(x).all().item()}", flush=True)
