@@ -8,13 +8,13 @@
 //   stepping             torchdiffeq fixed-grid solvers behind diffusion.py:631-639, 744-752
 //                        and flow.py:299-303, 371-382; EM loop diffusion.py:543-562
 //
-// Mapping (see ff_layout.h): a wavefront owns 32 MFMA columns.  In FF_MODE_STATE a column
-// is a sample.  In the divergence modes a sample owns 1 + T adjacent columns: its value
+// Mapping (see ff_layout.h): a wavefront owns TILE = 32 (v_mfma_f32_32x32x2) or 16
+// (v_mfma_f32_16x16x4) MFMA columns.  In FF_MODE_STATE a column is a sample.  In the divergence modes a sample owns 1 + T adjacent columns: its value
 // column and T tangent columns that carry forward-mode derivatives J.v through the same
 // weight operands (v = Hutchinson probe, or the D unit vectors for the exact trace); the
 // per-column contribution v . (J v) is integrated per lane and reduced once at the end.
-// Activations never leave registers: the 32x32 f32 accumulator tile of layer l, after
-// bias and SiLU, is the B operand of layer l+1.  Weights stream from L2 as the A operand
+// Activations never leave registers: the f32 accumulator tile of layer l (which starts from
+// the layer's bias), after the activation, is the B operand of layer l+1.  Weights stream from L2 as the A operand
 // (one 16-byte load per lane per 4 MFMAs) through a register ring that runs a fixed number
 // of chunks ahead of the MFMAs, across layer and evaluation boundaries.
 #pragma once
@@ -42,13 +42,6 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// sigmoid from the hardware exp2 / rcp units (each within 1 ulp): silu(a) = a*s,
-// silu'(a) = s + a*s*(1-s).
-__device__ __forceinline__ float sigmoidf_fast(float a)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __expf(-a));
 }
 
 // Weight / bias / table streams are read through buffer resources: the per-lane part of
@@ -618,10 +611,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         // are activated into P[(NB-1)*RB ..] behind the first MFMAs of the next layer, whose
         // phase A does not read the last k-block.
         float pend[RB];
-        BiasBlk<TILE> bias[2];
+        BiasBlk<TILE> bias[2];   // output layer only (tangent lanes read zeros through q16b)
         ActGroup ag[12];         // in-flight groups: [0,4) parked block of the previous layer, 4 + id % 8 own blocks
-        // (output layer only; tangent lanes read zeros through q16b)
-        auto bias1 = [&](const BiasBlk<TILE>& b, int r) { return b.reg(r); };
         // stages of the previous layer's parked block: group gi starts at slot gi*(16*PHYS/GPB)
         auto prev_slot = [&](auto mm) {
             constexpr int M = decltype(mm)::value;
@@ -718,7 +709,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             constexpr int blk = id / GPB, r0 = 4 * (id % GPB);
-                            net[blk * RB + r0 + i] = acc[blk].reg(r0 + i) + bias1(bias[blk & 1], r0 + i);
+                            net[blk * RB + r0 + i] = acc[blk].reg(r0 + i) + bias[blk & 1].reg(r0 + i);
                         }
                     }
                 }
@@ -726,7 +717,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             [&](const BlockAcc<TILE>& acc) {
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
-                    net[(NOB_OUT - 1) * RB + r] = acc.reg(r) + bias1(bias[(NOB_OUT - 1) & 1], r);
+                    net[(NOB_OUT - 1) * RB + r] = acc.reg(r) + bias[(NOB_OUT - 1) & 1].reg(r);
             },
             dbg);
 
