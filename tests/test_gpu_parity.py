@@ -658,3 +658,33 @@ def test_sample_sde_philox_public_api_and_sharded_helper():
     p = sm.sample_sde((20000, 16), steps=50, noise="philox")
     q = sm.sample_sde((20000, 16), steps=50)
     assert abs(float(p.mean() - q.mean())) < 0.05 * float(q.std()) and abs(float(p.std() / q.std()) - 1) < 0.03
+
+
+def test_custom_ops_pass_opcheck():
+    """The two torch custom ops that front the C ABI: schema, fake-tensor (meta) registration and functional
+    behaviour as torch.library.opcheck sees them (what torch.compile relies on to trace through them)."""
+    from flowfusion_amd import _native
+    from flowfusion_amd.fused import MODE_HUTCH, MODE_STATE
+    sm, _, _ = _seeded_score_model(5, 2, [64, 64], "VPSDE", True, 60)
+    net = sm._net()
+    x, cond = torch.randn(40, 5, device=DEV), torch.randn(40, 2, device=DEV)
+    opts = {"step_size": 0.25}
+    eps = float(sm.sde.epsilon)
+    tab = sm._ode_table(torch.tensor([1.0, eps]), "rk4", opts, MODE_STATE).to(DEV)
+    args = (x, cond, None, None, net.wpack(DEV, MODE_STATE), tab, None, None, None, None,
+            _native.plan_words(net.plan(MODE_STATE)), MODE_STATE)
+    tests = ("test_schema", "test_faketensor")
+    torch.library.opcheck(torch.ops.flowfusion_amd.mlp_ode.default, args, test_utils=tests)
+    e = torch.sign(torch.randn(40, 5, device=DEV))
+    tabh = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, MODE_HUTCH).to(DEV)
+    argsh = (x, cond, e, None, net.wpack(DEV, MODE_HUTCH), tabh, None, None, None, None,
+             _native.plan_words(net.plan(MODE_HUTCH)), MODE_HUTCH)
+    torch.library.opcheck(torch.ops.flowfusion_amd.mlp_ode.default, argsh, test_utils=tests)
+    # the adaptive-step op: one first-stage evaluation (slot 0 <- f(t, y)), one auxiliary output
+    step_rows = torch.zeros(3, tab.shape[1])
+    step_rows[0] = tab[0].cpu()
+    step_rows.view(torch.int32)[0, 3] = 0
+    step_rows[1, 8] = 1.0
+    argss = (x, cond, None, None, None, None, net.wpack(DEV, MODE_STATE), step_rows.to(DEV),
+             _native.plan_words(net.plan(MODE_STATE)), MODE_STATE, 1)
+    torch.library.opcheck(torch.ops.flowfusion_amd.mlp_ode_step.default, argss, test_utils=tests)
