@@ -75,6 +75,7 @@ class OdeArgs(ctypes.Structure):
         ("rng_noise_base", ctypes.c_int32),
         ("rng_seed", ctypes.c_uint64),
         ("rng_sample_offset", ctypes.c_int64),
+        ("jac_out", ctypes.c_void_p),
     ]
 
 
@@ -311,3 +312,49 @@ def mlp_ode_step(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[
 def _(x, cond, probe, k1, kl1, dlogp0, wpack, etab, plan, mode, n_aux, tangent_first=0, tangent_count=0):
     B = x.shape[0]
     return (x.new_empty(n_aux, B, x.shape[1]), x.new_empty(n_aux, B if mode != MODE_STATE else 0))
+
+
+@torch.library.custom_op("flowfusion_amd::mlp_rhs_jac", mutates_args=("jac",))
+def mlp_rhs_jac(x: torch.Tensor, cond: Optional[torch.Tensor], wpack: torch.Tensor, etab: torch.Tensor,
+                plan: List[int], tangent_first: int, tangent_count: int, jac: torch.Tensor) -> torch.Tensor:
+    """One right-hand-side evaluation with its Jacobian (ff_ode_args.jac_out): `etab` is one evaluation row
+    followed by the two auxiliary rows; returns rhs [B, D] and fills rows [tangent_first, +count) of
+    ``jac[b, j, i] = d rhs_i / d y_j``."""
+    if not x.is_cuda:
+        raise RuntimeError("flowfusion_amd::mlp_rhs_jac needs tensors on the GPU (there is no CPU path)")
+    dev = x.device
+    p = _plan_from_words(plan)
+    B, D = x.shape
+    rhs = torch.empty_like(x)
+    if B == 0:
+        return rhs
+    if tuple(jac.shape) != (B, D, D) or etab.shape[0] != 3 or etab.shape[1] != 32 + p.width:
+        raise RuntimeError("mlp_rhs_jac: jac must be [B, D, D] and etab one evaluation row + two auxiliary rows")
+    scratch = torch.empty_like(x)
+    dl = torch.empty(B, dtype=torch.float32, device=dev)
+    a = OdeArgs()
+    a.x_in = _chk(x, "x", dev)
+    a.x_out = scratch.data_ptr()
+    a.cond = _chk(cond, "cond", dev)
+    a.dlogp_out = dl.data_ptr()
+    a.wpack = _chk(wpack, "wpack", dev)
+    a.etab = _chk(etab, "etab", dev)
+    a.batch = B
+    a.n_evals = 1
+    a.mode = MODE_EXACT
+    a.tangent_first = tangent_first
+    a.tangent_count = tangent_count
+    a.aux_out[0] = rhs.data_ptr()
+    a.n_aux = 1
+    a.jac_out = _chk(jac, "jac", dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_ode_launch")
+    return rhs
+
+
+@mlp_rhs_jac.register_fake
+def _(x, cond, wpack, etab, plan, tangent_first, tangent_count, jac):
+    return torch.empty_like(x)

@@ -729,6 +729,17 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
             for (int r = 0; r < DREGS; ++r) dot = __builtin_fmaf(x[r], net[r], dot);
             div = is_tangent ? __builtin_fmaf(a_e, ee, b_e * dot) : 0.f;
+            // full Jacobian of the last evaluation's right-hand side (unit tangents): tangent column j holds
+            // d rhs / d y_j = a_e e_j + b_e dNET/dy_j; stored as row j of jac_out[sample]
+            if (args.jac_out && e == args.n_evals - 1 && is_tangent && col_live) {
+                const int tj = args.tangent_first + role - 1;
+                float* jp = args.jac_out + ((size_t)sample * D + tj) * D;
+#pragma unroll
+                for (int r = 0; r < DREGS; ++r) {
+                    const int d = feat_of_reg(TILE, r, qd);
+                    if (d < D) jp[d] = __builtin_fmaf(b_e, net[r], d == tj ? a_e : 0.f);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < DREGS; ++r) {

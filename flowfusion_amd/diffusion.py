@@ -28,6 +28,7 @@ from torch import nn
 from torch.distributions import Normal
 
 from . import adaptive, solvers
+from . import host_stepper, trace_estimators
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
 
 
@@ -207,8 +208,6 @@ class ScoreModel(nn.Module):
             with torch.set_grad_enabled(True):
                 x.requires_grad_(True)
                 return self.ode_drift(t, x, conditional=self.conditional)
-        if self.hutchpp or self.xtrace:
-            raise NotImplementedError("Hutch++ / XTrace trace estimators are outside the MI355X hot path")
         n = x.shape[0]
         with torch.set_grad_enabled(True):
             x.requires_grad_(True)
@@ -216,11 +215,38 @@ class ScoreModel(nn.Module):
             if self.hutch:
                 vjp = torch.autograd.grad(xdot, x, self.e, create_graph=True, retain_graph=True)[0]
                 div = (vjp * self.e).sum(dim=1)
+            elif self.hutchpp or self.xtrace:
+                # the reference detaches the estimator's products (diffusion.py:375-396): not differentiable
+                rows = [torch.autograd.grad(xdot[:, i].sum(), x, retain_graph=True)[0] for i in range(x.shape[1])]
+                A = torch.stack(rows, dim=1).transpose(1, 2).contiguous()          # A[b] = J[b]^T
+                div = self._estimate_divergence(A.detach(), x)
             else:
                 div = x.new_zeros(n)
                 for i in range(x.shape[1]):
                     div = div + torch.autograd.grad(xdot[:, i].sum(), x, create_graph=True, retain_graph=True)[0][:, i]
         return xdot, div.view(n, 1)
+
+    # -- Hutch++ / XTrace (reference :336-481) ---------------------------------------------------
+    def _probe_counts(self, D):
+        """(r, m) of Hutch++ and m of XTrace with the reference's clamps (:343-344, :409)."""
+        return (int(min(self.hpp_rank, D)), int(max(1, self.hpp_vector))), int(min(max(1, self.xt_vector), D))
+
+    def _estimate_divergence(self, A, x):
+        """Divergence estimate [B] from A[b] = J[b]^T with the stored probes (drawn afresh, like the reference's
+        fallback :350-353, :415-416, when none of the right shape are stored)."""
+        B, D = x.shape
+        (r, m), mx = self._probe_counts(D)
+        if self.hutchpp:
+            S, G = getattr(self, "S", None), getattr(self, "G", None)
+            if S is None or tuple(S.shape) != (r, B, D):
+                S = trace_estimators.draw_probes(r, x)
+            if G is None or tuple(G.shape) != (m, B, D):
+                G = trace_estimators.draw_probes(m, x)
+            return trace_estimators.hutchpp(A, S.to(A.device), G.to(A.device))
+        O = getattr(self, "O", None)
+        if O is None or tuple(O.shape) != (mx, B, D):
+            O = trace_estimators.draw_probes(mx, x)
+        return trace_estimators.xtrace(A, O.to(A.device))
 
     # -- fused path -----------------------------------------------------------------------------
     def _net(self) -> FusedNet:
@@ -425,9 +451,8 @@ class ScoreModel(nn.Module):
         net = self._net()
         self.prob = True
         self.conditional = conditional
-        if self.hutchpp or self.xtrace:
-            raise NotImplementedError("Hutch++ / XTrace trace estimators are outside the MI355X hot path "
-                                      "(use hutchinson=True or the exact trace)")
+        if (self.hutchpp or self.xtrace) and not self.hutch:
+            return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options)
         probe = None
         mode = MODE_EXACT
         if self.hutch:
@@ -438,6 +463,35 @@ class ScoreModel(nn.Module):
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
         xT, dlogp = self._solve(x0_samples, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe)
         return xT, dlogp.view(-1, 1)
+
+    def _solve_with_estimator(self, x0, conditional, atol, rtol, method, options):
+        """Hutch++ / XTrace log-density solve: the estimators factorise a sketch of the Jacobian at every
+        evaluation, so the table is run row by row (host_stepper.py) -- each row one fused launch that returns
+        the right-hand side and its whole Jacobian -- instead of in a single launch.  Probes are drawn once per
+        solve on the state's device, as the reference does (:703-719)."""
+        net = self._net()
+        if not x0.is_cuda:
+            raise RuntimeError("flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
+                               f"(got a tensor on {x0.device}); there is no CPU fallback")
+        B, D = x0.shape
+        (r, m), mx = self._probe_counts(D)
+        if self.hutchpp:
+            self.S = trace_estimators.draw_probes(r, x0)
+            self.G = trace_estimators.draw_probes(m, x0)
+        else:
+            # the reference stores max(1, xt_vecs) probes and redraws inside forward when that exceeds D (:719, :409-416)
+            self.O = trace_estimators.draw_probes(mx, x0)
+        x = x0.detach().to(torch.float32).contiguous()
+        stepper = host_stepper.RowStepper(net, x.device, conditional, lambda A: self._estimate_divergence(A, x))
+        t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
+        if method == "dopri5":
+            sched = lambda tr: self._schedule(tr, "ode")[:3]
+            solver = adaptive.Dopri5(stepper.make_step(sched, 1.0), True, rtol, atol, options)
+            y, lp = solver.integrate(float(t_span[0]), float(t_span[1]), x, torch.zeros(B, device=x.device))
+            self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
+        else:
+            y, lp = stepper.run_table(x, self._ode_table(t_span, method, options, MODE_EXACT))
+        return y, lp.view(-1, 1)
 
     @torch.no_grad()
     def log_prob(self, x0_samples, conditional=None, atol=1e-4, rtol=1e-4, method="dopri5",

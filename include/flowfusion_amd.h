@@ -148,6 +148,13 @@ typedef struct ff_ode_args {
      * into launches or shards: 1-, 2-, 4- and 8-GPU runs of one seed give the same samples. */
     uint64_t     rng_seed;
     int64_t      rng_sample_offset;
+    /* --- Jacobian output (FF_MODE_EXACT; optional) -----------------------------------------------
+     * jac_out[b][j][i] = d rhs_i / d y_j of the LAST evaluation row, for the unit tangents j of this
+     * launch (rows tangent_first .. tangent_first + count - 1; several launches fill the matrix).
+     * Row j is the product J^T e_j that the reference's Hutch++ / XTrace estimators obtain by
+     * reverse mode (`vjp_fn`, diffusion.py:360-372, 431-443); with the whole matrix on hand those
+     * estimators are small per-sample linear algebra (flowfusion_amd/trace_estimators.py). */
+    float*       jac_out;
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

@@ -164,6 +164,39 @@ def normal_log_prob(x, scale):
 
 # =================================================================================================
 # score model pieces
+def _hutchpp(A, S, G):
+    """diffusion.py:336-399.  A(V): probes [n,B,D] -> J^T V as columns [B,D,n]."""
+    Y = A(S)                                                          # :374-376
+    Q, _ = torch.linalg.qr(Y, mode="reduced")                         # :379
+    AQ = A(Q.permute(2, 0, 1))                                        # :383-386
+    low_rank = torch.einsum("bdk,bdk->b", Q, AQ)                      # :387
+    Gp = G.permute(1, 2, 0)                                           # :390
+    U = Gp - torch.einsum("bdk,bkm->bdm", Q, torch.einsum("bdk,bdm->bkm", Q, Gp))   # :391-393
+    AU = A(U.permute(2, 0, 1))                                        # :395-397
+    return low_rank + torch.einsum("bdm,bdm->b", U, AU) / float(G.shape[0])         # :398-400
+
+
+def _xtrace(A, O):
+    """diffusion.py:401-481 (leave-one-out Hutch++ from a single QR)."""
+    Y = A(O)                                                          # :446-448
+    Q, R = torch.linalg.qr(Y, mode="reduced")                         # :451
+    k = Q.shape[2]
+    Z = A(Q.permute(2, 0, 1))                                         # :456-459
+    H = torch.einsum("bdi,bdj->bij", Q, Z)                            # :461
+    W = torch.einsum("bdk,mbd->bkm", Q, O)                            # :463
+    T = torch.einsum("bdk,mbd->bkm", Z, O)                            # :465
+    St = torch.linalg.solve_triangular(R, torch.eye(k, dtype=R.dtype), upper=True)     # :467
+    St = St / torch.linalg.vector_norm(St, dim=-1, keepdim=True)      # :469
+    S = St.permute(0, 2, 1)                                           # :470
+    X = W - torch.sum(S * W, dim=1, keepdim=True) * S                 # :477
+    per_probe = (torch.diagonal(H, 0, 1, 2).sum(-1)[:, None]          # :473, :489
+                 - torch.sum(S * torch.einsum("bim,bmk->bik", H, S), dim=1)
+                 + torch.sum(W * S, dim=1) * torch.sum(S * R, dim=1)
+                 - torch.sum(T * X, dim=1)
+                 + torch.sum(X * torch.einsum("bim,bmk->bik", H, X), dim=1))
+    return per_probe.mean(dim=1)                                      # :491
+
+
 # =================================================================================================
 class ScoreOracle:
     """diffusion.py:124-815 restated over plain tensors."""
@@ -188,7 +221,8 @@ class ScoreOracle:
 
     def rhs(self, t, states, conditional=None, divergence: Optional[str] = None, e=None):
         """diffusion.py:281-334, 483-508: ``states=(x,)`` -> xdot ; with ``divergence`` in
-        {"hutch","exact"} ``states=(x, dlogp)`` -> (xdot, div[B,1])."""
+        {"hutch","exact","hutchpp","xtrace"} ``states=(x, dlogp)`` -> (xdot, div[B,1]).  ``e`` is the
+        Hutchinson probe [B,D], the pair (S [r,B,D], G [m,B,D]) for Hutch++, or O [m,B,D] for XTrace."""
         x = states[0]
         if divergence is None:
             with torch.no_grad():
@@ -202,6 +236,12 @@ class ScoreOracle:
                 div = torch.zeros(x.shape[0], dtype=x.dtype)
                 for i in range(x.shape[1]):
                     div = div + torch.autograd.grad(x_dot[:, i].sum(), x, retain_graph=True)[0][:, i]
+            elif divergence in ("hutchpp", "xtrace"):
+                # reverse-mode products A V = J^T V, one autograd call per probe (the reference batches
+                # them with vmap, :370-372); probes [n,B,D] in, columns [B,D,n] out
+                def A(V):
+                    return torch.stack([torch.autograd.grad(x_dot, x, v, retain_graph=True)[0] for v in V], dim=2).detach()
+                div = _hutchpp(A, *e) if divergence == "hutchpp" else _xtrace(A, e)
             else:
                 raise ValueError(divergence)
         return x_dot.detach(), div.detach().view(x.shape[0], 1)       # :505-506

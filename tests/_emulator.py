@@ -91,8 +91,9 @@ def _act_fn(plan):
     return act
 
 
-def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp):
-    """The kernel's evaluation loop over the first n_rows rows of etab (float64)."""
+def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp, jac=None, jac_first=0):
+    """The kernel's evaluation loop over the first n_rows rows of etab (float64).  ``jac`` ([B, D, D]): rows
+    jac_first.. of the last evaluation's transposed Jacobian are stored there (ff_ode_args.jac_out)."""
     D, C, NH, H = plan[0], plan[1], plan[2], plan[3]
     W1, hidden, Wo, bo, dx = decode_wpack(plan, wpack)
     W1x, W1c = W1[:, :D], W1[:, dx:dx + C]
@@ -122,6 +123,8 @@ def _run(plan, wpack, etab, n_rows, x, cond, V, noise, ks, kl, lp):
         if V is not None:
             dnet = (dh @ Wo.T)[:, :, :D]                        # [B,T,D]
             kl[slot] = a * (V * V).sum((1, 2)) + b * (V * dnet).sum((1, 2))
+            if jac is not None and e == n_rows - 1:
+                jac[:, jac_first:jac_first + V.shape[1], :] = (a * V + b * dnet).to(jac.dtype)
         if flags & 1:
             x = x + torch.einsum("s,sbd->bd", cout, ks)
             lp = lp + torch.einsum("s,sb->b", cout, kl)
@@ -196,3 +199,16 @@ def emulate_step(plan, wpack, etab, y, cond, probe, k1, kl1, lp0, mode, n_aux, f
         if mode:
             aux_lp[j] = uy * l0 + torch.einsum("s,sb->b", coefs[j], kl)
     return aux.float(), aux_lp.float()
+
+
+def emulate_rhs_jac(plan, wpack, rows, y, cond, first, count, jac):
+    """flowfusion_amd::mlp_rhs_jac: one evaluation row + two auxiliary rows; returns rhs (fp32) and fills
+    rows [first, first + count) of jac[b, j, i] = d rhs_i / d y_j."""
+    D = plan[0]
+    x = y.double()
+    B = x.shape[0]
+    ks = torch.zeros(7, B, D, dtype=torch.float64)
+    kl = torch.zeros(7, B, dtype=torch.float64)
+    _run(plan, wpack, rows, 1, x, cond, _tangents(plan, 2, None, B, first, count), None, ks, kl,
+         torch.zeros(B, dtype=torch.float64), jac=jac, jac_first=first)
+    return ks[0].float()

@@ -286,11 +286,73 @@ def make_hybrid(rd, rf):
         _save(f"hybrid_{name}", meta, **arrays)
 
 
+TRACE_CASES = {
+    # name: (score case, hpp_rank, hpp_vecs, xt_vecs)
+    "vp_sigma_cond": ("vp_sigma_cond", 2, 3, 3),
+    "ve_nosigma_cond32": ("ve_nosigma_cond32", 3, 2, 4),
+    "vp_nosigma_16d": ("vp_nosigma_16d", 1, 1, 2),
+}
+
+
+def make_trace_estimators(rd):
+    """Hutch++ and XTrace (diffusion.py:336-481): the reference's ScoreModel.forward with stored probes S, G, O
+    at three times, and hybrid log-densities (the oracle's fixed-grid stepper driving that forward)."""
+    from oracle import flowfusion_oracle as O
+
+    for name, (score_case, r, mv, xt) in TRACE_CASES.items():
+        mlp_case, sde_name, sde_kw, no_sigma = SCORE_CASES[score_case]
+        D, C, E, units = MLP_CASES[mlp_case]
+        torch.manual_seed(900 + D)
+        m = rd.MLP(n_dimensions=D, n_conditionals=C, embedding_dimensions=E, units=units)
+        sde = getattr(rd, sde_name)(**sde_kw)
+        sm = rd.ScoreModel(model=m, sde=sde, no_sigma=no_sigma, hpp_rank=r, hpp_vecs=mv, xt_vecs=xt)
+        B = 10
+        x = torch.randn(B, D) * 1.2
+        cond = torch.randn(B, C) if C else None
+        S = torch.sign(torch.randn(r, B, D))
+        G = torch.sign(torch.randn(mv, B, D))
+        Om = torch.sign(torch.randn(xt, B, D))
+        arrays = dict(x=x, S=S, G=G, O=Om, **_sd(sm))
+        if C:
+            arrays["cond"] = cond
+        sm.conditional = cond
+        sm.prob = True
+        sm.hutch = False
+        sm.S, sm.G, sm.O = S, G, Om
+
+        def rhs(kind):
+            sm.hutchpp, sm.xtrace = kind == "hpp", kind == "xt"
+            return lambda t, y: tuple(v.detach() for v in sm.forward(t, (y[0].detach(), y[1])))
+
+        for i, tval in enumerate((0.013, 0.41, 1.0)):
+            t = torch.tensor(tval)
+            arrays[f"t{i}"] = t
+            for kind in ("hpp", "xt", "exact"):
+                xd, div = rhs(kind)(t.clone(), (x.clone(), torch.zeros(B, 1)))
+                arrays[f"div_{kind}_{i}"] = div
+            arrays[f"xdot_{i}"] = xd
+        eps = float(sde.epsilon)
+        opts = {"step_size": (1.0 - eps) / 8}
+        for kind in ("hpp", "xt"):
+            xT, dlp = O.odeint_fixed(rhs(kind), (x, torch.zeros(B, 1)), torch.tensor([sde.epsilon, 1.0]), "rk4", opts)
+            arrays[f"lp_{kind}_rk4"] = dlp + torch.sum(sde.prior(xT.shape).log_prob(xT), dim=1, keepdim=True)
+        _save(f"trace_{name}", dict(D=D, C=C, E=E, units=units, sde=sde_name, sde_kw=sde_kw, no_sigma=no_sigma,
+                                    hpp_rank=r, hpp_vecs=mv, xt_vecs=xt, step_size=opts["step_size"]), **arrays)
+
+
 if __name__ == "__main__":
     rd, rf = _import_reference()
     torch.set_num_threads(4)
-    make_mlp_and_sde(rd)
-    make_score_rhs(rd)
-    make_sample_sde(rd)
-    make_flow(rf)
-    make_hybrid(rd, rf)
+    only = set(sys.argv[1:])          # e.g. `make_golden.py trace` regenerates one family
+    if not only or "mlp" in only:
+        make_mlp_and_sde(rd)
+    if not only or "score" in only:
+        make_score_rhs(rd)
+    if not only or "sde" in only:
+        make_sample_sde(rd)
+    if not only or "flow" in only:
+        make_flow(rf)
+    if not only or "hybrid" in only:
+        make_hybrid(rd, rf)
+    if not only or "trace" in only:
+        make_trace_estimators(rd)

@@ -688,3 +688,59 @@ def test_custom_ops_pass_opcheck():
     argss = (x, cond, None, None, None, None, net.wpack(DEV, MODE_STATE), step_rows.to(DEV),
              _native.plan_words(net.plan(MODE_STATE)), MODE_STATE, 1)
     torch.library.opcheck(torch.ops.flowfusion_amd.mlp_ode_step.default, argss, test_utils=tests)
+
+
+# ---- Hutch++ / XTrace (whole Jacobian per evaluation) -----------------------------------------------------------
+@pytest.mark.parametrize("D,C,units,sde", [(5, 3, [64, 100], "VPSDE"), (16, 0, [256] * 4, "VPSDE"), (32, 8, [96, 96], "VESDE"),
+                                           (40, 0, [512, 300], "VPSDE")])
+def test_jacobian_output_against_autograd(D, C, units, sde):
+    """ff_ode_args.jac_out: row j of jac[b] is J[b]^T e_j of the right-hand side, from unit tangents (one launch for
+    5 dimensions, 15 + 1 for 16, several for 32 and 40), against autograd on the product's plain-torch drift."""
+    from flowfusion_amd import host_stepper
+    sm, _, _ = _seeded_score_model(D, C, units, sde, False, 70 + D)
+    B = 37
+    x = torch.randn(B, D, device=DEV)
+    cond = torch.randn(B, C, device=DEV) if C else None
+    t = torch.tensor([0.37])
+    a, b, c1, _ = sm._schedule(t, "ode")
+    got = {}
+    st = host_stepper.RowStepper(sm._net(), x.device, cond, lambda A: got.setdefault("A", A).new_zeros(B))
+    rhs, _ = st.rhs_div(x, float(a[0]), float(b[0]), c1[0])
+    f = lambda v: sm.ode_drift(t.to(DEV)[0], v, conditional=cond)
+    with torch.enable_grad():
+        J = torch.autograd.functional.jacobian(lambda v: f(v).sum(0), x, vectorize=True)       # [i, b, j]
+    want = J.permute(1, 2, 0)                                                                       # [b, j, i]
+    assert _state_err(rhs, f(x).detach().cpu()) < STATE_TOL
+    assert _state_err(got["A"], want.cpu()) < 5e-5
+
+
+@pytest.mark.parametrize("name", golden_names("trace_"))
+def test_hutchpp_and_xtrace_log_prob_against_reference_fixtures(name, monkeypatch):
+    """solve_odes_forward / log_prob with hutchpp=True and xtrace=True on the GPU, probes as in the fixture (the
+    draw is intercepted), against the log-densities the reference's forward produced under the oracle's RK4
+    (samples with linearly dependent probes left out, see tests/test_trace_estimators.py)."""
+    from flowfusion_amd import trace_estimators as TE
+    from tests.test_trace_estimators import well_posed
+    meta, a = load_golden(name)
+    x, cond = a["x"].to(DEV), (a["cond"].to(DEV) if "cond" in a else None)
+    opts = {"step_size": meta["step_size"]}
+    for kind, kw, probes, want in (("hutchpp", dict(hutchpp=True, hpp_rank=meta["hpp_rank"], hpp_vecs=meta["hpp_vecs"]),
+                                    [a["S"], a["G"]], a["lp_hpp_rk4"]),
+                                   ("xtrace", dict(xtrace=True, xt_vecs=meta["xt_vecs"]), [a["O"]], a["lp_xt_rk4"])):
+        sm = score_model(meta, a, DEV, **kw)
+        queue = [p.to(DEV) for p in probes]
+        monkeypatch.setattr(TE, "draw_probes", lambda n, like: queue.pop(0))
+        lp = sm.log_prob(x, conditional=cond, method="rk4", options=opts)
+        assert not queue and lp.shape == (x.shape[0], 1)
+        ok = well_posed(probes[0])
+        err = max_rel(lp.cpu()[ok], want[ok], floor=1.0)
+        assert err < 5e-5, (name, kind, err)
+    # reference defaults (adaptive dopri5), fresh random probes: runs natively and lands near the exact trace
+    monkeypatch.undo()
+    sm = score_model(meta, a, DEV, hutchpp=True, hpp_rank=meta["D"], hpp_vecs=1)
+    if meta["sde"] != "VESDE":
+        lp_pp = sm.log_prob(x, conditional=cond)
+        sm.hutchpp = False
+        lp_exact = sm.log_prob(x, conditional=cond)
+        # rank = D: the sketch spans everything, the estimate IS the trace
+        assert max_rel(lp_pp.cpu(), lp_exact.cpu(), floor=1.0) < 2e-3

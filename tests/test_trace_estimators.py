@@ -1,0 +1,118 @@
+"""Hutch++ / XTrace divergence estimators (reference diffusion.py:336-481): CPU tier.
+
+Pinned by fixtures generated from the reference's own ``ScoreModel.forward`` with stored probes
+(tests/golden/trace_*.npz: pointwise estimates at three times, and log-densities from the oracle's
+fixed-grid stepper driving that forward).  Samples whose probe vectors happen to be linearly dependent
+(+-1 entries in 5 dimensions collide often) are left out: there the QR basis, and with it the estimate,
+depends on the factorisation's arbitrary completion, in the reference as much as anywhere."""
+import pytest
+import torch
+
+from flowfusion_amd import _native, adaptive, host_stepper, trace_estimators as TE
+from flowfusion_amd.fused import MODE_EXACT
+from oracle import flowfusion_oracle as O
+from tests import _emulator as E
+from tests._util import golden_names, load_golden, score_model, score_oracle
+
+CASES = golden_names("trace_")
+
+
+def well_posed(P):
+    """[B] bool: the probes P[:, b, :] of sample b are linearly independent."""
+    return torch.tensor([int(torch.linalg.matrix_rank(P[:, b, :])) == P.shape[0] for b in range(P.shape[1])])
+
+
+def _close(got, want, mask, tol=2e-5):
+    got, want = got.reshape(-1)[mask].double(), want.reshape(-1)[mask].double()
+    assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (got, want)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_estimators_match_reference(name):
+    meta, a = load_golden(name)
+    so = score_oracle(meta, a)
+    x, cond = a["x"], a.get("cond")
+    ok_s, ok_o = well_posed(a["S"]), well_posed(a["O"])
+    zero = torch.zeros(x.shape[0], 1)
+    for i in range(3):
+        t = a[f"t{i}"]
+        _close(so.rhs(t, (x, zero), cond, "hutchpp", (a["S"], a["G"]))[1], a[f"div_hpp_{i}"], ok_s, 1e-6)
+        _close(so.rhs(t, (x, zero), cond, "xtrace", a["O"])[1], a[f"div_xt_{i}"], ok_o, 1e-6)
+    # the hybrid log-densities: same stepper, oracle right-hand side instead of the reference's
+    opts = {"step_size": meta["step_size"]}
+    times = torch.stack([so.sde.epsilon.to(torch.float32), torch.tensor(1.0)])
+    for kind, probes, ok in (("hutchpp", (a["S"], a["G"]), ok_s), ("xtrace", a["O"], ok_o)):
+        xT, dlp = O.odeint_fixed(lambda t, y: so.rhs(t, y, cond, kind, probes), (x, zero), times, "rk4", opts)
+        lp = dlp + torch.sum(O.normal_log_prob(xT, so.sde.prior_scale()), dim=1, keepdim=True)
+        _close(lp, a["lp_hpp_rk4" if kind == "hutchpp" else "lp_xt_rk4"], ok, 2e-6)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_estimators_and_torch_forward_match_reference(name):
+    """trace_estimators on a whole Jacobian, and ScoreModel.forward's plain-torch branch, against the fixtures."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a, hutchpp=True, hpp_rank=meta["hpp_rank"], hpp_vecs=meta["hpp_vecs"], xt_vecs=meta["xt_vecs"])
+    x, cond = a["x"], a.get("cond")
+    ok_s, ok_o = well_posed(a["S"]), well_posed(a["O"])
+    sm.conditional, sm.prob = cond, True
+    sm.S, sm.G, sm.O = a["S"], a["G"], a["O"]
+    for i in range(3):
+        t = a[f"t{i}"]
+        J = torch.autograd.functional.jacobian(lambda v: sm.ode_drift(t, v, conditional=cond).sum(0), x, vectorize=True)
+        A = J.permute(1, 2, 0).contiguous()                      # A[b, j, i] = d xdot_i / d x_j
+        _close(TE.hutchpp(A, a["S"], a["G"]), a[f"div_hpp_{i}"], ok_s)
+        _close(TE.xtrace(A, a["O"]), a[f"div_xt_{i}"], ok_o)
+        sm.hutchpp, sm.xtrace = True, False
+        xd, div = sm.forward(t.clone(), (x.clone(), torch.zeros(x.shape[0], 1)))
+        _close(div.detach(), a[f"div_hpp_{i}"], ok_s)
+        torch.testing.assert_close(xd.detach(), a[f"xdot_{i}"], rtol=1e-5, atol=1e-5)
+        sm.hutchpp, sm.xtrace = False, True
+        _close(sm.forward(t.clone(), (x.clone(), torch.zeros(x.shape[0], 1)))[1].detach(), a[f"div_xt_{i}"], ok_o)
+
+
+def _cpu_stepper(sm, cond, div_fn):
+    net = sm._net()
+    plan = _native.plan_words(net.plan(MODE_EXACT))
+    wpack = net.wpack("cpu", MODE_EXACT)
+    launcher = lambda y, rows, first, count, jac: E.emulate_rhs_jac(plan, wpack, rows, y, cond, first, count, jac)
+    return host_stepper.RowStepper(net, "cpu", cond, div_fn, launcher=launcher)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_row_stepper_reproduces_reference_log_density(name, built_library):
+    """Host logic of the estimator solves: the evaluation table run row by row (kernel semantics emulated, whole
+    Jacobian per row from unit tangents in the launches the product would use) with the estimators on top gives
+    the fixtures' log-densities; the same interpreter as a step function drives the adaptive solver to the oracle's
+    dopri5 result."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a)
+    so = score_oracle(meta, a, torch.float64)
+    x, cond = a["x"], a.get("cond")
+    eps = float(sm.sde.epsilon)
+    table = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", {"step_size": meta["step_size"]}, MODE_EXACT)
+    for kind, fn, probes, want in (("hutchpp", lambda A: TE.hutchpp(A, a["S"], a["G"]), (a["S"], a["G"]), a["lp_hpp_rk4"]),
+                                   ("xtrace", lambda A: TE.xtrace(A, a["O"]), a["O"], a["lp_xt_rk4"])):
+        ok = well_posed(probes[0] if kind == "hutchpp" else probes)
+        st = _cpu_stepper(sm, cond, fn)
+        xT, dlp = st.run_table(x, table)
+        assert st.n_evals == table.shape[0]
+        lp = dlp.view(-1, 1) + sm.sde.prior(xT.shape).log_prob(xT).sum(1, keepdim=True)
+        _close(lp, want, ok, 3e-5)
+    # adaptive: Hutch++ through the Dopri5 driver vs the oracle's dopri5 with the same probes (float64 oracle).
+    # (Not for the VE model without sigma normalisation: its random-init right-hand side at t = 1e-5 drives any
+    # adaptive controller to vanishing steps.)
+    if meta["sde"] == "VESDE":
+        return
+    # only the well-posed samples take part: the error norm is global, an ill-defined estimate would steer everyone
+    ok = well_posed(a["S"])
+    xs, cs = x[ok], (None if cond is None else cond[ok])
+    Ss, Gs = a["S"][:, ok].contiguous(), a["G"][:, ok].contiguous()
+    st = _cpu_stepper(sm, cs, lambda A: TE.hutchpp(A, Ss, Gs))
+    solver = adaptive.Dopri5(st.make_step(lambda tr: sm._schedule(tr, "ode")[:3], 1.0), True, 1e-4, 1e-4, None)
+    y, lp = solver.integrate(eps, 1.0, xs.clone(), torch.zeros(xs.shape[0]))
+    ry, rlp = so.solve_odes_forward(xs.double(), None if cs is None else cs.double(), "dopri5", None, "hutchpp",
+                                    (Ss.double(), Gs.double()), atol=1e-4, rtol=1e-4)
+    assert solver.n_accepted >= 2
+    everyone = torch.ones(xs.shape[0], dtype=torch.bool)
+    _close(y, ry.float(), everyone.repeat_interleave(xs.shape[1]), 2e-4)
+    _close(lp, rlp, everyone, 2e-4)
