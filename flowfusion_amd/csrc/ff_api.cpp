@@ -13,7 +13,7 @@ static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
 
 static thread_local int t_last_hip_error = 0;
 
-extern "C" const char* ff_version(void) { return "flowfusion_amd 0.1 gfx950 (f32 MFMA 32x32x2, in-register layer chaining)"; }
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.1 gfx950 (f32 MFMA 16x16x4 / 32x32x2, in-register layer chaining)"; }
 
 extern "C" int ff_kernel_count(void) { return ff::g_n_kernels; }
 
