@@ -340,6 +340,33 @@ def make_trace_estimators(rd):
                                     hpp_rank=r, hpp_vecs=mv, xt_vecs=xt, step_size=opts["step_size"]), **arrays)
 
 
+def make_population(rd):
+    """PopulationModelDiffusion[Conditional] (diffusion.py:1466-1848): state_dict layout and ``sample_sde`` with
+    the random stream captured (the wrappers always take 100 steps, whatever ``steps`` says)."""
+    for name, C in (("pop_4d", 0), ("popcond_4d_c2", 2)):
+        D = 4
+        torch.manual_seed(950 + C)
+        m = rd.MLP(n_dimensions=D, n_conditionals=C, embedding_dimensions=6, units=[64, 48])
+        shift, scale = torch.randn(D), torch.rand(D) + 0.5
+        if C:
+            cshift, cscale = torch.randn(C), torch.rand(C) + 0.5
+            pm = rd.PopulationModelDiffusionConditional(model=m, sde=rd.VESDE(), shift=shift, scale=scale,
+                                                        conditional_shift=cshift, conditional_scale=cscale)
+        else:
+            pm = rd.PopulationModelDiffusion(model=m, sde=rd.VESDE(), shift=shift, scale=scale)
+        B = 12
+        cond = torch.randn(B, C) * 2 + 1 if C else None
+        torch.manual_seed(777)
+        out = pm.sample_sde((B, D), cond, steps=7) if C else pm.sample_sde((B, D), steps=7)
+        torch.manual_seed(777)
+        x_prior = pm.sde.prior([D]).sample([B])
+        noise = torch.stack([torch.randn_like(x_prior) for _ in range(100)])
+        arrays = dict(x_prior=x_prior, noise=noise, out=out, **_sd(pm))
+        if C:
+            arrays["cond"] = cond
+        _save(name, dict(D=D, C=C, E=6, units=[64, 48], seed=777), **arrays)
+
+
 if __name__ == "__main__":
     rd, rf = _import_reference()
     torch.set_num_threads(4)
@@ -356,3 +383,5 @@ if __name__ == "__main__":
         make_hybrid(rd, rf)
     if not only or "trace" in only:
         make_trace_estimators(rd)
+    if not only or "pop" in only:
+        make_population(rd)

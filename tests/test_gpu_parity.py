@@ -744,3 +744,29 @@ def test_hutchpp_and_xtrace_log_prob_against_reference_fixtures(name, monkeypatc
         lp_exact = sm.log_prob(x, conditional=cond)
         # rank = D: the sketch spans everything, the estimate IS the trace
         assert max_rel(lp_pp.cpu(), lp_exact.cpu(), floor=1.0) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["pop_4d", "popcond_4d_c2"])
+def test_population_wrapper_sample_sde_against_reference_stream(name):
+    """PopulationModelDiffusion[Conditional].sample_sde through the product wrapper (conditional normalisation,
+    the hard-wired 100 steps, output affine; diffusion.py:1587-1609, 1786-1815), the reference's random stream fed
+    in where the score model would draw it."""
+    from tests.test_host_logic import _population_model
+    meta, a = load_golden(name)
+    pm = _population_model(meta, a, DEV)
+    sm = pm.score_model
+    it = iter(a["noise"])
+    seen = {}
+
+    def replay(shape, conditional=None, steps=100):
+        seen["steps"], seen["shape"] = steps, tuple(shape)
+        return sm._sample_sde_from(a["x_prior"].to(DEV), lambda like: next(it).to(DEV), conditional, steps)
+
+    sm.sample_sde = replay
+    B, Dd = a["x_prior"].shape
+    if meta["C"]:
+        out = pm.sample_sde((B, Dd), a["cond"].to(DEV), steps=7)
+    else:
+        out = pm.sample_sde((B, Dd), steps=7)
+    assert seen == {"steps": 100, "shape": (B, Dd)}
+    assert _state_err(out, a["out"]) < STATE_TOL

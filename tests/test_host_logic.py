@@ -421,3 +421,39 @@ def test_emulated_euler_maruyama_with_philox_noise(built_library):
     z = torch.from_numpy(normals(seed, off, B, 6, list(range(steps)))).double()
     want = so.sample_sde(x.double(), [z[i] for i in range(steps)], cond.double(), steps=steps)
     torch.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
+
+
+# ---- PopulationModel wrappers: reference state_dict layout and sample_sde (fixtures pop*.npz) -----------------
+def _population_model(meta, a, device="cpu"):
+    m = D.MLP(n_dimensions=meta["D"], n_conditionals=meta["C"], embedding_dimensions=meta["E"], units=meta["units"])
+    if meta["C"]:
+        pm = D.PopulationModelDiffusionConditional(model=m, sde=D.VESDE())
+    else:
+        pm = D.PopulationModelDiffusion(model=m, sde=D.VESDE())
+    data = {"x_prior", "noise", "out", "cond"}
+    pm.load_state_dict({k: v for k, v in a.items() if k not in data}, strict=True)      # exactly the reference's keys
+    return pm.to(device).eval()
+
+
+@pytest.mark.parametrize("name", ["pop_4d", "popcond_4d_c2"])
+def test_population_wrappers_load_reference_state_and_sample(name, built_library):
+    meta, a = load_golden(name)
+    pm = _population_model(meta, a)
+    sm = pm.score_model
+    cond = a.get("cond")
+    cn = None if cond is None else (cond - pm.conditional_shift) / pm.conditional_scale      # diffusion.py:1808-1809
+    T, eps = torch.as_tensor(sm.sde.T, dtype=torch.float32), sm.sde.epsilon.detach()
+    ts, dt = solvers.plan_euler_maruyama(T, eps, 100)                 # the wrappers always take 100 steps (:1608, :1810)
+    aa, bb, c1, g = sm._schedule(ts, "sde")
+    n = ts.numel()
+    flags = torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32)
+    flags[-1] = solvers.FLAG_STEP_END
+    cout = torch.zeros(n, 8)
+    cout[:, 0] = dt
+    plan = solvers.EvalPlan(t_eval=ts, sign=1.0, slot=torch.zeros(n, dtype=torch.int32), flags=flags,
+                            cin=torch.zeros(n, 8), cout=cout, n_steps=n)
+    table = solvers.build_table(plan, aa, bb, c1, sm._net().width(MODE_STATE), gn=g * (-dt) ** 0.5,
+                                noise_idx=torch.arange(n))
+    x, _ = _emulate_score(sm, a["x_prior"], table, MODE_STATE, cn, noise=a["noise"])
+    got = x * pm.scale.double() + pm.shift.double()                   # :1606-1609
+    assert max_rel(got, a["out"], floor=a["out"].abs().max().item()) < 3e-5
