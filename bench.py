@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU")
-    ap.add_argument("--cpu-batch", type=int, default=16384, help="samples for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-batch", type=int, default=32768, help="samples for the CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
     ap.add_argument("--single-device", action="store_true",
