@@ -165,6 +165,8 @@ class Dopri5:
         while t_end > t_hi:
             if n_steps >= self.max_num_steps:
                 raise RuntimeError(f"max_num_steps exceeded ({n_steps}>={self.max_num_steps})")
+            if dt == dt:
+                dt = min(max(dt, self.min_step), self.max_step)      # every attempt starts from a clamped step
             ta, tb = t_hi, t_hi + dt
             if not (ta + dt > ta):      # also catches dt = NaN after a non-finite error estimate
                 raise RuntimeError(f"underflow in dt {dt}")

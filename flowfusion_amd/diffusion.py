@@ -262,27 +262,34 @@ class ScoreModel(nn.Module):
                                    c_col0=E + m.n_dimensions, act=act)
         return self._fused
 
-    def _schedule(self, t: torch.Tensor, sde_form: str):
+    def _schedule_inputs(self):
+        """Host copies of everything `_schedule` reads (SDE, embedding frequencies, first layer).  Taken once
+        per solve: the adaptive driver calls `_schedule` at every attempted step, and each device-to-host copy
+        would wait for the kernel in flight."""
+        m = self.model
+        w0, b0 = self._net().first_layer_cpu()
+        return (copy.deepcopy(self.sde).to("cpu"), m.W.detach().to("cpu", torch.float32),
+                m.pi.detach().to("cpu", torch.float32), w0, b0)
+
+    def _schedule(self, t: torch.Tensor, sde_form: str, host=None):
         """Per-evaluation scalars (a, b) and first-layer bias c1 for real times ``t`` (fp32, CPU).
 
         ODE (diffusion.py:276-278): xdot = f - 0.5 g^2 score  ->  a = f/x, b = -0.5 g^2 [/ sigma]
         reverse SDE (:553):         f - g^2 score             ->  b = -g^2 [/ sigma]
         with f = a(t) x for all three SDEs (:905, :1131, :1316).  Returns also g (for the noise).
         """
-        sde = copy.deepcopy(self.sde).to("cpu")
+        sde, W, pi, w0, b0 = host if host is not None else self._schedule_inputs()
         one = torch.ones(t.numel(), 1, dtype=torch.float32)
         a = sde.drift(t, one).reshape(-1)
         g = sde.diffusion(t, one).reshape(-1)
         b = -(0.5 * g ** 2) if sde_form == "ode" else -(g ** 2)
         if not self.no_sigma:
             b = b / sde.sigma(t).reshape(-1)
-        m = self.model
-        W = m.W.detach().to("cpu", torch.float32)
-        pi = m.pi.detach().to("cpu", torch.float32)
         arg = t[:, None] * W[None, :] * 2 * pi
         emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
-        w0, b0 = self._net().first_layer_cpu()
-        c1 = emb @ w0[:, : emb.shape[1]].T + b0
+        # broadcast product + sum rather than a matmul: a BLAS call this small costs ~0.5-8 ms when it wakes a
+        # 128-thread pool on a many-core host (measured), the elementwise form stays on the calling thread
+        c1 = (emb[:, None, :] * w0[None, :, : emb.shape[1]]).sum(-1) + b0
         return a, b, c1, g
 
     def _check_inputs(self, x, what):
@@ -303,7 +310,8 @@ class ScoreModel(nn.Module):
         if method == "dopri5":
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
-            sched = lambda tr: self._schedule(tr, "ode")[:3]
+            host = self._schedule_inputs()
+            sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             step = net.make_step(sched, sign, mode, x.device, cond=cond, probe=probe)
             solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
@@ -485,7 +493,8 @@ class ScoreModel(nn.Module):
         stepper = host_stepper.RowStepper(net, x.device, conditional, lambda A: self._estimate_divergence(A, x))
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
         if method == "dopri5":
-            sched = lambda tr: self._schedule(tr, "ode")[:3]
+            host = self._schedule_inputs()
+            sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             solver = adaptive.Dopri5(stepper.make_step(sched, 1.0), True, rtol, atol, options)
             y, lp = solver.integrate(float(t_span[0]), float(t_span[1]), x, torch.zeros(B, device=x.device))
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}

@@ -56,10 +56,11 @@ class _FlowBase(nn.Module):
             object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1, act=act))
         return self._fused
 
-    def _schedule(self, t):
+    def _schedule(self, t, first=None):
         """(a, b, c1) for real times t (fp32, CPU): xdot = NET([x, t, cond]) -> a = 0, b = 1,
-        c1 = w_t * t + bias of the first layer (flow.py:112-118)."""
-        w0, b0 = self._net().first_layer_cpu()
+        c1 = w_t * t + bias of the first layer (flow.py:112-118).  ``first`` = host copy of the first layer,
+        taken once per solve by the adaptive path (a device-to-host copy per step would wait for the kernel)."""
+        w0, b0 = first if first is not None else self._net().first_layer_cpu()
         D = self.target_dimension
         c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
         return torch.zeros_like(t), torch.ones_like(t), c1
@@ -79,7 +80,8 @@ class _FlowBase(nn.Module):
                 raise AssertionError("affine epilogues are applied by the caller on the adaptive path")
             t = t_span.double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
-            step = net.make_step(self._schedule, sign, mode, x.device, cond=cond, probe=probe)
+            first = net.first_layer_cpu()
+            step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
             solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),

@@ -460,7 +460,10 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
     t_lo = t_hi = t0
     last = None
     while t[-1] > t_hi:
+        dt = dt.clamp(min_step, max_step)                         # every attempt starts from a clamped step
         ta, tb = t_hi, t_hi + dt
+        if not bool(ta + dt > ta):
+            raise AssertionError(f"underflow in dt {float(dt)}")  # torchdiffeq's assertion
         ta32, dt32, tb32 = ta.to(dty), dt.to(dty), tb.to(dty)
         ks = [f]
         for alpha, beta in zip(_DP5_ALPHA, _DP5_BETA):
