@@ -279,6 +279,10 @@ class ScoreModel(nn.Module):
         with f = a(t) x for all three SDEs (:905, :1131, :1316).  Returns also g (for the noise).
         """
         sde, W, pi, w0, b0 = host if host is not None else self._schedule_inputs()
+        with solvers.host_threads():
+            return self._schedule_on_host(t, sde_form, sde, W, pi, w0, b0)
+
+    def _schedule_on_host(self, t, sde_form, sde, W, pi, w0, b0):
         one = torch.ones(t.numel(), 1, dtype=torch.float32)
         a = sde.drift(t, one).reshape(-1)
         g = sde.diffusion(t, one).reshape(-1)
@@ -404,10 +408,18 @@ class ScoreModel(nn.Module):
                                    cin=zeros8[start:stop], cout=cout[start:stop], n_steps=stop - start)
             tables.append(solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
                                               gn=gn[start:stop], noise_idx=torch.arange(stop - start)).to(dev))
-        main = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
         bufs = [torch.empty(min(chunk, n), batch, x.shape[1], device=dev, dtype=torch.float32)
                 for _ in range(min(2, len(bounds)))]
+        if len(bounds) == 1:
+            # everything fits one buffer: nothing to overlap, draw on the current stream
+            for i in range(n):
+                bufs[0][i] = draw(x)
+            x, _, status = net.integrate(x, tables[0], MODE_STATE, cond=conditional, noise=bufs[0][:n])
+            if int(status.item()) & 1:
+                print("Diffusion is not stable, NaN were produced. Stopped sampling.")
+            return x
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
         ready = [None] * len(bounds)
         freed = [None] * len(bufs)
 

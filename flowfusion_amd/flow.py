@@ -62,8 +62,9 @@ class _FlowBase(nn.Module):
         taken once per solve by the adaptive path (a device-to-host copy per step would wait for the kernel)."""
         w0, b0 = first if first is not None else self._net().first_layer_cpu()
         D = self.target_dimension
-        c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
-        return torch.zeros_like(t), torch.ones_like(t), c1
+        with solvers.host_threads():
+            c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
+            return torch.zeros_like(t), torch.ones_like(t), c1
 
     def _table(self, t_span, method, options, mode):
         plan = solvers.plan_ode(t_span, method, options)

@@ -23,6 +23,26 @@ from typing import Callable, Optional, Sequence
 
 import torch
 
+class host_threads:
+    """Context for the small host-side computations of this package (schedules, tables): cap torch's intra-op
+    threads.  On a many-core host the default pool (e.g. 128 threads) takes milliseconds to wake for operands of
+    a few thousand elements -- longer than the kernels these tables feed at notebook batch sizes."""
+
+    def __init__(self, n: int = 4):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.n:
+            torch.set_num_threads(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
 ROW_HDR = 32          # words in the row header (FF_ROW_HDR)
 MAX_SLOTS = 7         # stage slots on chip (FF_MAX_SLOTS)
 FLAG_STEP_END = 1
