@@ -284,6 +284,31 @@ def test_exact_trace_partition_equals_single_launch(D, units):
         assert _logp_err(dl, dl1.cpu()) < 2e-6
 
 
+def test_many_dimensions_on_a_256_wide_network():
+    """48 dimensions, 256-wide hidden layers: the 64-dimension instance of the 256-wide kernels (not the 512-wide
+    ones); sampling, exact-trace log-density (four launches of unit tangents), Euler-Maruyama."""
+    from flowfusion_amd import flow as Fm, _native
+    torch.manual_seed(61)
+    f = Fm.ODEFlow(48, [256, 256], target_shift=torch.randn(48), target_scale=torch.rand(48) + 0.5).eval()
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    fo, fo64 = flow_oracle(sd), flow_oracle(sd, torch.float64)
+    f = f.to(DEV)
+    assert _native.lib().ff_kernel_name(f._net().plan(0).kernel_id) == b"mlp_ode_m16_h256_d16_c4_t0"
+    xT = torch.randn(150, 48)
+    opts = {"step_size": 0.05}
+    assert _state_err(f.sample(xT.to(DEV), method="rk4", options=opts), fo.sample(xT, None, "rk4", opts)) < STATE_TOL
+    x = xT[:20] * f.target_scale.cpu() + f.target_shift.cpu()
+    lp = f.log_prob(x.to(DEV), method="rk4", options=opts)
+    assert _logp_err(lp, fo64.log_prob(x.double(), None, "rk4", opts).float()) < LOGP_TOL
+    sm, so32, _ = _seeded_score_model(40, 0, [256, 200], "VESDE", False, 62)
+    torch.manual_seed(9)
+    prior = sm.sde.prior([40]).sample([64]).to(DEV)
+    noise = [torch.randn_like(prior).cpu() for _ in range(10)]
+    it = iter(noise)
+    got = sm._sample_sde_from(prior, lambda like: next(it).to(DEV), None, 10)
+    assert _state_err(got, so32.sample_sde(prior.cpu(), noise, None, steps=10)) < STATE_TOL
+
+
 def test_config4_flow_64d_5x512():
     """BASELINE config 4 shape (64-dim flow matching, MLP 5x512) on the 16x16x4 kernels: sampling
     with RK4 and fixed-step Dormand-Prince, and the Hutchinson log-density extension."""

@@ -45,6 +45,8 @@ def test_plan_selection_and_errors(built_library):
     assert (p.tile, p.width, p.dregs) == (32, 128, 4)
     p = _native.make_plan(32, 8, [200, 100], MODE_STATE)          # ragged widths pad to the max
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
+    p = _native.make_plan(48, 0, [256, 256], MODE_EXACT)          # many dimensions on a 256-wide net stay 256 wide
+    assert (p.tile, p.width, p.dregs) == (16, 256, 16)
     p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
     assert (p.tile, p.width, p.dregs) == (16, 512, 16)
     p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
