@@ -309,6 +309,20 @@ def test_many_dimensions_on_a_256_wide_network():
     assert _state_err(got, so32.sample_sde(prior.cpu(), noise, None, steps=10)) < STATE_TOL
 
 
+def test_many_conditional_inputs():
+    """24 conditional inputs (more than the 16 most kernels carry): the 32-conditional catch-all kernels."""
+    sm, so32, so64 = _seeded_score_model(6, 24, [128, 96], "VPSDE", False, 63)
+    torch.manual_seed(10)
+    B = 90
+    z, cond = torch.randn(B, 6), torch.randn(B, 24)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 16}
+    x0, _ = sm.sample_ode_from_base(z.to(DEV), conditional=cond.to(DEV), method="rk4", options=opts)
+    assert _state_err(x0, so32.sample_ode_from_base(z, cond, "rk4", opts)) < STATE_TOL
+    lp = sm.log_prob(z[:30].to(DEV), conditional=cond[:30].to(DEV), method="rk4", options=opts)
+    ref = so64.log_prob(z[:30].double(), cond[:30].double(), "rk4", opts, "exact")
+    assert _logp_err(lp, ref.float()) < LOGP_TOL
+
+
 def test_config4_flow_64d_5x512():
     """BASELINE config 4 shape (64-dim flow matching, MLP 5x512) on the 16x16x4 kernels: sampling
     with RK4 and fixed-step Dormand-Prince, and the Hutchinson log-density extension."""

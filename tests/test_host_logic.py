@@ -47,6 +47,8 @@ def test_plan_selection_and_errors(built_library):
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
     p = _native.make_plan(48, 0, [256, 256], MODE_EXACT)          # many dimensions on a 256-wide net stay 256 wide
     assert (p.tile, p.width, p.dregs) == (16, 256, 16)
+    p = _native.make_plan(6, 24, [128, 128], MODE_HUTCH)          # more than 16 conditional inputs: the catch-all
+    assert (p.tile, p.width, p.cregs) == (16, 512, 8)
     p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
     assert (p.tile, p.width, p.dregs) == (16, 512, 16)
     p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
@@ -55,6 +57,8 @@ def test_plan_selection_and_errors(built_library):
         _native.make_plan(64, 0, [1024] * 2, MODE_STATE)          # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
         _native.make_plan(80, 0, [64], MODE_STATE)                # more dimensions than any compiled kernel
+    with pytest.raises(NotImplementedError):
+        _native.make_plan(4, 33, [64], MODE_STATE)                # more conditional inputs than any compiled kernel
     # launch argument checking happens before any HIP call
     bad = _native.OdeArgs()
     rc = built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(bad), None)
