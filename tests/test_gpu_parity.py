@@ -809,3 +809,34 @@ def test_population_wrapper_sample_sde_against_reference_stream(name):
         out = pm.sample_sde((B, Dd), steps=7)
     assert seen == {"steps": 100, "shape": (B, Dd)}
     assert _state_err(out, a["out"]) < STATE_TOL
+
+
+def test_reference_default_constructor_shapes():
+    """`MLP()` with the reference's default arguments (2 dimensions, ONE conditional input, one hidden layer of 128;
+    diffusion.py:32-40) and the flows' defaults (1 dimension, hidden [128, 128]; flow.py:37-44): a single hidden
+    layer means no hidden-to-hidden layer at all on the kernel."""
+    from flowfusion_amd import diffusion as Dm, flow as Fm
+    from oracle import flowfusion_oracle as O
+    torch.manual_seed(17)
+    sm = Dm.ScoreModel(Dm.MLP(), Dm.VPSDE(), no_sigma=True).eval()
+    params = O.mlp_params_from_state_dict({k: v.detach().clone() for k, v in sm.state_dict().items()})
+    so32 = O.ScoreOracle(params, O.VP(), no_sigma=True)
+    so64 = O.ScoreOracle(params, O.VP(dtype=torch.float64), no_sigma=True, dtype=torch.float64)
+    sm = sm.to(DEV)
+    B = 200
+    z, cond = torch.randn(B, 2), torch.randn(B, 1)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 20}
+    x0, _ = sm.sample_ode_from_base(z.to(DEV), conditional=cond.to(DEV), method="rk4", options=opts)
+    assert _state_err(x0, so32.sample_ode_from_base(z, cond, "rk4", opts)) < STATE_TOL
+    lp = sm.log_prob(z.to(DEV), conditional=cond.to(DEV), method="rk4", options=opts)
+    assert _logp_err(lp, so64.log_prob(z.double(), cond.double(), "rk4", opts, "exact").float()) < LOGP_TOL
+    torch.manual_seed(7)
+    a = sm.sample_sde((64, 2), conditional=cond[:64].to(DEV), steps=10)
+    assert a.shape == (64, 2) and torch.isfinite(a).all()
+    f = Fm.ODEFlow().eval()
+    fo64 = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()}, torch.float64)
+    f = f.to(DEV)
+    xT = torch.randn(100, 1)
+    o2 = {"step_size": 0.1}
+    assert _state_err(f.sample(xT.to(DEV), method="rk4", options=o2), fo64.sample(xT.double(), None, "rk4", o2).float()) < STATE_TOL
+    assert _logp_err(f.log_prob(xT.to(DEV), method="rk4", options=o2), fo64.log_prob(xT.double(), None, "rk4", o2).float()) < LOGP_TOL
