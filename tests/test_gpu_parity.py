@@ -840,3 +840,100 @@ def test_reference_default_constructor_shapes():
     o2 = {"step_size": 0.1}
     assert _state_err(f.sample(xT.to(DEV), method="rk4", options=o2), fo64.sample(xT.double(), None, "rk4", o2).float()) < STATE_TOL
     assert _logp_err(f.log_prob(xT.to(DEV), method="rk4", options=o2), fo64.log_prob(xT.double(), None, "rk4", o2).float()) < LOGP_TOL
+
+
+def test_random_shapes_against_oracle():
+    """Seeded sweep over network shapes (dimension, conditionals, depth, ragged widths), SDEs, solvers, modes and batch
+    sizes, so that every compiled kernel family is reached by some case: sampling and log-density against the
+    oracle."""
+    import random
+    from flowfusion_amd import diffusion as Dm, _native
+    from oracle import flowfusion_oracle as O
+    rnd = random.Random(2024)
+    kernels = set()
+    for case in range(48):
+        wmax = rnd.choice([40, 64, 100, 128, 200, 256, 384, 512])
+        depth = rnd.choice([1, 2, 3, 5])
+        units = [rnd.randint(max(8, wmax // 2), wmax) for _ in range(depth)]
+        units[rnd.randrange(depth)] = wmax
+        D = rnd.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48, 64])
+        C = rnd.choice([0, 0, 1, 4, 9, 16, 17, 32])
+        sde = rnd.choice(["VPSDE", "VESDE", "SUBVPSDE"])
+        no_sigma = rnd.random() < 0.5
+        method, nsteps = rnd.choice([("euler", 12), ("midpoint", 8), ("rk4", 6), ("dopri5_fixed", 4), ("heun3", 6)])
+        B = rnd.choice([1, 5, 16, 33, 100])
+        torch.manual_seed(1000 + case)
+        sm = Dm.ScoreModel(Dm.MLP(D, C, rnd.choice([2, 8, 10]), units), getattr(Dm, sde)(), no_sigma=no_sigma).eval()
+        params = O.mlp_params_from_state_dict({k: v.detach().clone() for k, v in sm.state_dict().items()})
+        sde_o = {"VPSDE": O.VP, "VESDE": O.VE, "SUBVPSDE": O.SubVP}[sde](dtype=torch.float64)
+        so = O.ScoreOracle(params, sde_o, no_sigma=no_sigma, dtype=torch.float64)
+        sm = sm.to(DEV)
+        z = torch.randn(B, D)
+        cond = torch.randn(B, C) if C else None
+        cd = None if cond is None else cond.to(DEV)
+        c64 = None if cond is None else cond.double()
+        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+        tag = (case, D, C, units, sde, no_sigma, method, B)
+        x0, _ = sm.sample_ode_from_base(z.to(DEV), conditional=cd, method=method, options=opts)
+        ref = so.sample_ode_from_base(z.double(), c64, method, opts)
+        assert _state_err(x0, ref.float()) < STATE_TOL, tag
+        kernels.add(_native.lib().ff_kernel_name(sm._net().plan(0).kernel_id))
+        mode = rnd.choice(["hutch", "exact"])
+        sm.hutch = mode == "hutch"
+        xd = torch.randn(B, D) * 0.5
+        lp = sm.log_prob(xd.to(DEV), conditional=cd, method=method, options=opts)
+        e = sm.e.cpu().double() if sm.hutch else None
+        lref = so.log_prob(xd.double(), c64, method, opts, mode, e)
+        assert _logp_err(lp, lref.float()) < LOGP_TOL, tag + (mode,)
+        kernels.add(_native.lib().ff_kernel_name(sm._net().plan(1 if sm.hutch else 2).kernel_id))
+    assert len(kernels) >= 16, sorted(kernels)
+
+
+def test_random_flow_shapes_against_oracle():
+    """The same kind of sweep for the flows (conditional or not, affine target / conditional maps, exact trace in as
+    many launches as the dimension needs) and for Euler-Maruyama with an injected random stream."""
+    import random
+    from flowfusion_amd import flow as Fm
+    rnd = random.Random(4048)
+    for case in range(24):
+        wmax = rnd.choice([32, 64, 128, 256, 512])
+        depth = rnd.choice([1, 2, 4])
+        units = [rnd.randint(max(8, wmax // 2), wmax) for _ in range(depth)]
+        units[0] = wmax
+        D = rnd.choice([1, 2, 5, 16, 20, 33, 64])
+        C = rnd.choice([0, 0, 1, 6, 16, 30])
+        torch.manual_seed(2000 + case)
+        kw = dict(target_dimension=D, hidden_units=units, target_shift=torch.randn(D), target_scale=torch.rand(D) + 0.5)
+        if C:
+            kw.update(conditional_dimension=C, conditional_shift=torch.randn(C), conditional_scale=torch.rand(C) + 0.5)
+        f = (Fm.ConditionalODEFlow if C else Fm.ODEFlow)(**kw).eval()
+        fo64 = flow_oracle({k: v.detach().clone() for k, v in f.state_dict().items()}, torch.float64)
+        f = f.to(DEV)
+        B = rnd.choice([1, 7, 32, 65])
+        method, nsteps = rnd.choice([("euler", 10), ("rk4", 5), ("midpoint", 6)])
+        opts = {"step_size": 1.0 / nsteps}
+        xT = torch.randn(B, D)
+        cond = torch.randn(B, C) * 2 if C else None
+        args = (xT.to(DEV),) + ((cond.to(DEV),) if C else ())
+        tag = (case, D, C, units, method, B)
+        got = f.sample(*args, method=method, options=opts)
+        ref = fo64.sample(xT.double(), None if cond is None else cond.double(), method, opts)
+        assert _state_err(got, ref.float()) < STATE_TOL, tag
+        x = xT * f.target_scale.cpu() + f.target_shift.cpu()
+        args = (x.to(DEV),) + ((cond.to(DEV),) if C else ())
+        lp = f.log_prob(*args, method=method, options=opts)
+        lref = fo64.log_prob(x.double(), None if cond is None else cond.double(), method, opts)
+        assert _logp_err(lp, lref.float()) < LOGP_TOL, tag
+    for case in range(8):
+        D, C = rnd.choice([(2, 0), (6, 3), (16, 0), (33, 20), (64, 0)])
+        units = rnd.choice([[64], [128, 100], [256] * 3, [512, 256]])
+        sde = rnd.choice(["VPSDE", "VESDE", "SUBVPSDE"])
+        sm, so32, _ = _seeded_score_model(D, C, units, sde, rnd.random() < 0.5, 3000 + case)
+        B, steps = rnd.choice([3, 40, 129]), rnd.choice([5, 17])
+        torch.manual_seed(case)
+        prior = sm.sde.prior([D]).sample([B]).cpu()
+        cond = torch.randn(B, C) if C else None
+        noise = [torch.randn(B, D) for _ in range(steps)]
+        it = iter(noise)
+        got = sm._sample_sde_from(prior.to(DEV), lambda like: next(it).to(DEV), None if cond is None else cond.to(DEV), steps)
+        assert _state_err(got, so32.sample_sde(prior, noise, cond, steps=steps)) < STATE_TOL, (case, D, C, units, sde, B, steps)
