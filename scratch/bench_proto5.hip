@@ -1,0 +1,157 @@
+// Scratch (planning for a later round): what would a split-precision layer chain
+// run at?  One 256x256 layer = 8 row tiles x 16 k-steps of v_mfma_f32_32x32x16_bf16 on 32 samples per
+// wavefront; fp32 operands are cut into three bf16 parts (hi, mid, lo) and the six products that matter
+// (hi.hi, hi.mid, hi.lo, mid.hi, mid.mid, lo.hi) are accumulated in fp32.  Activations stay in registers
+// (accumulator tile -> SiLU -> split -> B fragments of the next layer); weight fragments are read from LDS
+// (filled once: timing only, every row tile reuses the same 48 KB -- the L2 -> LDS refill of a real kernel,
+// 16 B/clk/CU, is not modelled).  Results are meaningless; the time per layer is the point.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
+
+__device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// top halves of (a, b) -> one register of two bf16 (a low, b high): truncation split
+__device__ __forceinline__ unsigned pack_hi(float a, float b)
+{
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
+}
+__device__ __forceinline__ float top(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u); }
+
+// SiLU of 16 accumulator registers, then the three-way split, packed as the B fragments of two k-steps
+template <bool ACT>
+__device__ __forceinline__ void finish_tile(const f32x16& acc, u32x4 (&o0)[3], u32x4 (&o1)[3])
+{
+    float h[16], m[16], l[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = acc[i];
+        if constexpr (ACT) {
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504f));
+            v = v * r;
+        }
+        h[i] = v;
+        const float r1 = v - top(v);
+        m[i] = r1;
+        l[i] = r1 - top(r1);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o0[0][j] = pack_hi(h[2 * j], h[2 * j + 1]);
+        o0[1][j] = pack_hi(m[2 * j], m[2 * j + 1]);
+        o0[2][j] = pack_hi(l[2 * j], l[2 * j + 1]);
+        o1[0][j] = pack_hi(h[8 + 2 * j], h[8 + 2 * j + 1]);
+        o1[1][j] = pack_hi(m[8 + 2 * j], m[8 + 2 * j + 1]);
+        o1[2][j] = pack_hi(l[8 + 2 * j], l[8 + 2 * j + 1]);
+    }
+}
+
+template <int NPROD, bool ACT>
+__device__ __forceinline__ void layer(const u32x4* lds, int lane, const u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3])
+{
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const u32x4 wh = lds[((ks * 3 + 0 + tile * 5) % 48) * 64 + lane];     // a different fragment per tile
+            a0 = mm(wh, cur[ks][0], a0);
+            if constexpr (NPROD >= 3) {
+                const u32x4 wm = lds[((ks * 3 + 1 + tile * 5) % 48) * 64 + lane];
+                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wm, cur[ks][0], a0);
+                if constexpr (NPROD >= 6) {
+                    const u32x4 wl = lds[((ks * 3 + 2 + tile * 5) % 48) * 64 + lane];
+                    a1 = mm(wh, cur[ks][2], a1);
+                    a0 = mm(wm, cur[ks][1], a0);
+                    a1 = mm(wl, cur[ks][0], a1);
+                }
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
+        finish_tile<ACT>(acc, nxt[2 * tile], nxt[2 * tile + 1]);
+    }
+}
+
+template <int NPROD, bool ACT>
+__global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
+                                              float* __restrict__ xout, int pairs)
+{
+    extern __shared__ u32x4 lds[];
+    for (int i = threadIdx.x; i < 16 * 3 * 64; i += 256) lds[i] = ((const u32x4*)wsrc)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    u32x4 A[16][3], B[16][3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
+    for (int it = 0; it < pairs; ++it) {       // two layers per iteration: A -> B -> A
+        layer<NPROD, ACT>(lds, lane, A, B);
+        layer<NPROD, ACT>(lds, lane, B, A);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s += __builtin_bit_cast(float, A[ks][p][0] << 16);
+    xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NPROD, bool ACT>
+void run(const unsigned* dw, const float* dx, float* dy, int pairs, const char* what)
+{
+    const int nwg = 256 * 4;               // one workgroup per CU at a time (48 KB LDS, 4 waves), 4 rounds
+    auto kern = k<NPROD, ACT>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 49152, 0, dw, dx, dy, 2);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 49152, 0, dw, dx, dy, pairs);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double layers = 2.0 * pairs;
+    const double sample_layers = (double)nwg * 4 * 32 * layers;            // (sample, layer) pairs processed
+    const double flop32 = sample_layers * 2.0 * 256 * 256;                  // what the fp32 kernel counts
+    printf("%-34s %8.2f ms  %7.1f fp32-equivalent TFLOP/s  (%.2fx of 142)   %.0f MFMA/layer/wave\n", what, ms,
+           flop32 / ms / 1e9, flop32 / ms / 1e9 / 142.0, 128.0 * NPROD);
+}
+
+int main(int argc, char** argv)
+{
+    const int pairs = argc > 1 ? atoi(argv[1]) : 100;
+    std::vector<unsigned> hw(16 * 3 * 64 * 4);
+    srand(2);
+    for (auto& v : hw) {                    // two small bf16 per word
+        const unsigned short a = 0x3C00 + (rand() & 0xFF), b = 0xBC00 + (rand() & 0xFF);
+        v = a | ((unsigned)b << 16);
+    }
+    std::vector<float> hx(2048);
+    for (auto& v : hx) v = (rand() / (float)RAND_MAX - 0.5f) * 0.5f;
+    unsigned* dw; float *dx, *dy;
+    CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dy, (size_t)1024 * 256 * 4));
+    CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    run<6, true>(dw, dx, dy, pairs, "6 products, SiLU + split");
+    run<6, false>(dw, dx, dy, pairs, "6 products, split only");
+    run<3, true>(dw, dx, dy, pairs, "3 products, SiLU + split");
+    run<1, true>(dw, dx, dy, pairs, "1 product (plain bf16), SiLU");
+    return 0;
+}
