@@ -53,7 +53,8 @@ __device__ __forceinline__ void finish_tile(const f32x16& acc, u32x4 (&o0)[3], u
     }
 }
 
-template <int NPROD, bool ACT>
+// SRC: LDS-resident fragments (lds) or, with GLOBAL, this layer's own 384 KB streamed by every wavefront from L2
+template <int NPROD, bool ACT, bool GLOBAL = false>
 __device__ __forceinline__ void layer(const u32x4* lds, int lane, const u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3])
 {
 #pragma unroll
@@ -63,14 +64,14 @@ __device__ __forceinline__ void layer(const u32x4* lds, int lane, const u32x4 (&
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const u32x4 wh = lds[((ks * 3 + 0 + tile * 5) % 48) * 64 + lane];     // a different fragment per tile
+            const u32x4 wh = lds[(GLOBAL ? (tile * 48 + ks * 3 + 0) : ((ks * 3 + 0 + tile * 5) % 48)) * 64 + lane];     // a different fragment per tile
             a0 = mm(wh, cur[ks][0], a0);
             if constexpr (NPROD >= 3) {
-                const u32x4 wm = lds[((ks * 3 + 1 + tile * 5) % 48) * 64 + lane];
+                const u32x4 wm = lds[(GLOBAL ? (tile * 48 + ks * 3 + 1) : ((ks * 3 + 1 + tile * 5) % 48)) * 64 + lane];
                 a1 = mm(wh, cur[ks][1], a1);
                 a0 = mm(wm, cur[ks][0], a0);
                 if constexpr (NPROD >= 6) {
-                    const u32x4 wl = lds[((ks * 3 + 2 + tile * 5) % 48) * 64 + lane];
+                    const u32x4 wl = lds[(GLOBAL ? (tile * 48 + ks * 3 + 2) : ((ks * 3 + 2 + tile * 5) % 48)) * 64 + lane];
                     a1 = mm(wh, cur[ks][2], a1);
                     a0 = mm(wm, cur[ks][1], a0);
                     a1 = mm(wl, cur[ks][0], a1);
@@ -82,6 +83,31 @@ __device__ __forceinline__ void layer(const u32x4* lds, int lane, const u32x4 (&
         for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
         finish_tile<ACT>(acc, nxt[2 * tile], nxt[2 * tile + 1]);
     }
+}
+
+template <int NPROD, bool ACT>
+__global__ __launch_bounds__(256, 1) void kg(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
+                                               float* __restrict__ xout, int pairs)
+{
+    const int lane = threadIdx.x & 63;
+    const u32x4* w = (const u32x4*)wsrc;
+    u32x4 A[16][3], B[16][3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
+    for (int it = 0; it < pairs; ++it) {
+        layer<NPROD, ACT, true>(w, lane, A, B);
+        layer<NPROD, ACT, true>(w + 8 * 48 * 64, lane, B, A);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s += __builtin_bit_cast(float, A[ks][p][0] << 16);
+    xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 template <int NPROD, bool ACT>
@@ -111,11 +137,11 @@ __global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ wsrc, c
     xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NPROD, bool ACT>
+template <int NPROD, bool ACT, bool GLOBAL = false>
 void run(const unsigned* dw, const float* dx, float* dy, int pairs, const char* what)
 {
     const int nwg = 256 * 4;               // one workgroup per CU at a time (48 KB LDS, 4 waves), 4 rounds
-    auto kern = k<NPROD, ACT>;
+    auto kern = GLOBAL ? kg<NPROD, ACT> : k<NPROD, ACT>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -137,7 +163,7 @@ void run(const unsigned* dw, const float* dx, float* dy, int pairs, const char* 
 int main(int argc, char** argv)
 {
     const int pairs = argc > 1 ? atoi(argv[1]) : 100;
-    std::vector<unsigned> hw(16 * 3 * 64 * 4);
+    std::vector<unsigned> hw((size_t)2 * 8 * 48 * 64 * 4);       // two layers x 8 tiles x 48 fragments of 1 KiB
     srand(2);
     for (auto& v : hw) {                    // two small bf16 per word
         const unsigned short a = 0x3C00 + (rand() & 0xFF), b = 0xBC00 + (rand() & 0xFF);
@@ -153,5 +179,7 @@ int main(int argc, char** argv)
     run<6, false>(dw, dx, dy, pairs, "6 products, split only");
     run<3, true>(dw, dx, dy, pairs, "3 products, SiLU + split");
     run<1, true>(dw, dx, dy, pairs, "1 product (plain bf16), SiLU");
+    run<6, true, true>(dw, dx, dy, pairs, "6 products, weights from L2");
+    run<3, true, true>(dw, dx, dy, pairs, "3 products, weights from L2");
     return 0;
 }
