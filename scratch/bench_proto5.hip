@@ -110,6 +110,72 @@ __global__ __launch_bounds__(256, 1) void kg(const unsigned* __restrict__ wsrc, 
     xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Weight pipeline as a real kernel would have it: tile-major, the 48 fragments (48 KiB) of the next row tile are
+// fetched from L2 by the four wavefronts together (12 KiB each, held in registers while the current tile is
+// computed), written to the other LDS buffer, one barrier per tile.
+template <bool ACT>
+__global__ __launch_bounds__(256, 1) void kp(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
+                                               float* __restrict__ xout, int pairs)
+{
+    extern __shared__ u32x4 lds[];                      // 2 x 3072 fragments-lanes of 16 B = 96 KiB
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32x4* w = (const u32x4*)wsrc;
+    u32x4 A[16][3], B[16][3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
+    // tile 0 of layer 0 into buffer 0
+#pragma unroll
+    for (int f = 0; f < 12; ++f) lds[(wv * 12 + f) * 64 + lane] = w[(wv * 12 + f) * 64 + lane];
+    __syncthreads();
+    auto one_layer = [&](int layer_idx, const u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3]) {
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            const int buf = tile & 1;                    // 8 tiles per layer: parity carries across layers
+            // next tile's fragments (wrapping over the two layers' 16 tiles): global -> registers
+            const int nt = (layer_idx * 8 + tile + 1) & 15;
+            u32x4 pre[12];
+#pragma unroll
+            for (int f = 0; f < 12; ++f) pre[f] = w[(nt * 48 + wv * 12 + f) * 64 + lane];
+            const u32x4* lb = lds + buf * 3072;
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const u32x4 wh = lb[(ks * 3 + 0) * 64 + lane], wm = lb[(ks * 3 + 1) * 64 + lane], wl = lb[(ks * 3 + 2) * 64 + lane];
+                a0 = mm(wh, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wm, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][2], a1);
+                a0 = mm(wm, cur[ks][1], a0);
+                a1 = mm(wl, cur[ks][0], a1);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = a0[r] + a1[r];
+            finish_tile<ACT>(acc, nxt[2 * tile], nxt[2 * tile + 1]);
+            u32x4* ob = lds + (buf ^ 1) * 3072;
+#pragma unroll
+            for (int f = 0; f < 12; ++f) ob[(wv * 12 + f) * 64 + lane] = pre[f];
+            __syncthreads();
+        }
+    };
+    for (int it = 0; it < pairs; ++it) {
+        one_layer(0, A, B);
+        one_layer(1, B, A);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s += __builtin_bit_cast(float, A[ks][p][0] << 16);
+    xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int NPROD, bool ACT>
 __global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
                                               float* __restrict__ xout, int pairs)
@@ -179,6 +245,24 @@ int main(int argc, char** argv)
     run<6, false>(dw, dx, dy, pairs, "6 products, split only");
     run<3, true>(dw, dx, dy, pairs, "3 products, SiLU + split");
     run<1, true>(dw, dx, dy, pairs, "1 product (plain bf16), SiLU");
+    {
+        const int nwg = 256 * 4;
+        auto kern = kp<true>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 98304, 0, dw, dx, dy, 2);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 98304, 0, dw, dx, dy, pairs);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop32 = (double)nwg * 4 * 32 * 2.0 * pairs * 2.0 * 256 * 256;
+        printf("%-34s %8.2f ms  %7.1f fp32-equivalent TFLOP/s  (%.2fx of 142)\n", "6 products, L2->LDS pipeline", ms,
+               flop32 / ms / 1e9, flop32 / ms / 1e9 / 142.0);
+    }
     run<6, true, true>(dw, dx, dy, pairs, "6 products, weights from L2");
     run<3, true, true>(dw, dx, dy, pairs, "3 products, weights from L2");
     return 0;
