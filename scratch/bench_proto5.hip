@@ -9,9 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 
 __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c)
@@ -103,6 +106,173 @@ __global__ __launch_bounds__(256, 1) void kg(const unsigned* __restrict__ wsrc, 
         layer<NPROD, ACT, true>(w + 8 * 48 * 64, lane, B, A);
     }
     float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s += __builtin_bit_cast(float, A[ks][p][0] << 16);
+    xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// Hand-ordered variant of the LDS-resident chain: fragments of k-step ks+1 are read while the six MFMAs of
+// k-step ks issue; the activation + split of the PREVIOUS tile's accumulator is spread over the first eight
+// k-steps of the current tile (two registers per step), so the VALU work sits in the MFMAs' shadow; a masked
+// sched_barrier per k-step pins the MFMA / LDS order and leaves VALU placement to the scheduler.
+template <bool ACT>
+__device__ __forceinline__ void split_pair(float v0, float v1, u32x4 (&o)[3], int j)
+{
+    if constexpr (ACT) {
+        v0 = v0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v0 * -1.44269504f));
+        v1 = v1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v1 * -1.44269504f));
+    }
+    const float m0 = v0 - top(v0), m1 = v1 - top(v1);
+    const float l0 = m0 - top(m0), l1 = m1 - top(m1);
+    o[0][j] = pack_hi(v0, v1);
+    o[1][j] = pack_hi(m0, m1);
+    o[2][j] = pack_hi(l0, l1);
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256, 1) void kh(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
+                                               float* __restrict__ xout, int pairs)
+{
+    extern __shared__ u32x4 lds[];
+    for (int i = threadIdx.x; i < 16 * 3 * 64; i += 256) lds[i] = ((const u32x4*)wsrc)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    u32x4 A[16][3], B[16][3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
+    f32x16 p0, p1;                                  // the previous tile's two partial accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+    // one layer; `prev_out` receives the previous tile's fragments: for tile 0 that is the LAST tile of the layer
+    // before (k-steps 14, 15 of `cur`, complete before this tile reaches k-step 14), otherwise tile-1 of `nxt`
+    auto one_layer = [&](u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3]) {
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+            u32x4 wh = lds[((0 + tile * 5) % 48) * 64 + lane], wm = lds[((1 + tile * 5) % 48) * 64 + lane],
+                  wl = lds[((2 + tile * 5) % 48) * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                u32x4 nh = wh, nm = wm, nl = wl;
+                if (ks < 15) {
+                    nh = lds[((ks * 3 + 3 + tile * 5) % 48) * 64 + lane];
+                    nm = lds[((ks * 3 + 4 + tile * 5) % 48) * 64 + lane];
+                    nl = lds[((ks * 3 + 5 + tile * 5) % 48) * 64 + lane];
+                }
+                a0 = mm(wh, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wm, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][2], a1);
+                a0 = mm(wm, cur[ks][1], a0);
+                a1 = mm(wl, cur[ks][0], a1);
+                if (ks < 8) {                          // previous tile: registers 2ks, 2ks+1
+                    const float v0 = p0[2 * ks] + p1[2 * ks], v1 = p0[2 * ks + 1] + p1[2 * ks + 1];
+                    if (tile == 0) split_pair<ACT>(v0, v1, cur[14 + (ks >> 2)], ks & 3);
+                    else split_pair<ACT>(v0, v1, nxt[2 * (tile - 1) + (ks >> 2)], ks & 3);
+                }
+                wh = nh; wm = nm; wl = nl;
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200);   // VALU / SALU / trans may move; MFMA, DS pinned
+            }
+            p0 = a0; p1 = a1;
+        }
+    };
+    for (int it = 0; it < pairs; ++it) {
+        one_layer(A, B);
+        one_layer(B, A);
+    }
+    float s = p0[0] + p1[3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) s += __builtin_bit_cast(float, A[ks][p][0] << 16);
+    xout[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <bool ACT>
+__global__ __launch_bounds__(256, 1) void khp(const unsigned* __restrict__ wsrc, const float* __restrict__ xin,
+                                               float* __restrict__ xout, int pairs)
+{
+    // as kh, plus the real weight path: THREE LDS buffers of one row tile's 48 fragments; at the start of tile t the
+    // four wavefronts start the LDS-DMA (global_load_lds, 12 fragments each, no registers) of tile t+2; at the end
+    // of tile t a counted wait (vmcnt(12): everything but the newest tile's DMA) and one raw barrier publish tile t+1
+    extern __shared__ u32x4 lds[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: addresses stay in SGPRs
+    const u32x4* w = (const u32x4*)wsrc;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+        lds[(wv * 12 + f) * 64 + lane] = w[(wv * 12 + f) * 64 + lane];                              // tile 0
+        lds[3072 + (wv * 12 + f) * 64 + lane] = w[48 * 64 + (wv * 12 + f) * 64 + lane];            // tile 1
+    }
+    __syncthreads();
+    u32x4 A[16][3], B[16][3];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
+    f32x16 p0, p1;                                  // the previous tile's two partial accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+    // one layer; `prev_out` receives the previous tile's fragments: for tile 0 that is the LAST tile of the layer
+    // before (k-steps 14, 15 of `cur`, complete before this tile reaches k-step 14), otherwise tile-1 of `nxt`
+    auto one_layer = [&](auto lidx, u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3]) {
+        constexpr int LI = decltype(lidx)::value;
+#pragma unroll
+        for (int tile = 0; tile < 8; ++tile) {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+            constexpr int GT = LI * 8;                  // tiles done before this layer (mod 48 = 16 stored tiles x 3 buffers)
+            const u32x4* lb = lds + ((GT + tile) % 3) * 3072;
+            const u32x4* wn = w + (size_t)((LI * 8 + tile + 2) & 15) * 48 * 64 + (wv * 12) * 64;          // wave-uniform
+            u32x4 wh = lb[0 * 64 + lane], wm = lb[1 * 64 + lane], wl = lb[2 * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                u32x4 nh = wh, nm = wm, nl = wl;
+                if (ks < 15) {
+                    nh = lb[(ks * 3 + 3) * 64 + lane];
+                    nm = lb[(ks * 3 + 4) * 64 + lane];
+                    nl = lb[(ks * 3 + 5) * 64 + lane];
+                }
+                if (ks == 0) {                                   // LDS-DMA of tile t+2 into the buffer tile t-1 used
+#pragma unroll
+                    for (int fr = 0; fr < 12; ++fr)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(wn + fr * 64 + lane),
+                                                         (lptr_t)(lds + ((GT + tile + 2) % 3) * 3072 + (wv * 12 + fr) * 64), 16, 0, 0);
+                }
+                a0 = mm(wh, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wm, cur[ks][0], a0);
+                a1 = mm(wh, cur[ks][2], a1);
+                a0 = mm(wm, cur[ks][1], a0);
+                a1 = mm(wl, cur[ks][0], a1);
+                if (ks < 8) {                          // previous tile: registers 2ks, 2ks+1
+                    const float v0 = p0[2 * ks] + p1[2 * ks], v1 = p0[2 * ks + 1] + p1[2 * ks + 1];
+                    if (tile == 0) split_pair<ACT>(v0, v1, cur[14 + (ks >> 2)], ks & 3);
+                    else split_pair<ACT>(v0, v1, nxt[2 * (tile - 1) + (ks >> 2)], ks & 3);
+                }
+                wh = nh; wm = nm; wl = nl;
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200);   // VALU / SALU / trans may move; MFMA, DS pinned
+            }
+            p0 = a0; p1 = a1;
+            __builtin_amdgcn_s_waitcnt(0x007c);            // vmcnt(12) lgkmcnt(0): all but the newest tile's DMA have landed
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    for (int it = 0; it < pairs; ++it) {
+        one_layer(std::integral_constant<int, 0>{}, A, B);
+        one_layer(std::integral_constant<int, 1>{}, B, A);
+    }
+    float s = p0[0] + p1[3];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
@@ -245,6 +415,42 @@ int main(int argc, char** argv)
     run<6, false>(dw, dx, dy, pairs, "6 products, split only");
     run<3, true>(dw, dx, dy, pairs, "3 products, SiLU + split");
     run<1, true>(dw, dx, dy, pairs, "1 product (plain bf16), SiLU");
+    {
+        const int nwg = 256 * 4;
+        auto kern = kh<true>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 49152, 0, dw, dx, dy, 2);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 49152, 0, dw, dx, dy, pairs);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop32 = (double)nwg * 4 * 32 * 2.0 * pairs * 2.0 * 256 * 256;
+        printf("%-34s %8.2f ms  %7.1f fp32-equivalent TFLOP/s  (%.2fx of 142)\n", "6 products, hand-ordered (LDS)", ms,
+               flop32 / ms / 1e9, flop32 / ms / 1e9 / 142.0);
+    }
+    {
+        const int nwg = 256 * 4;
+        auto kern = khp<true>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 147456, 0, dw, dx, dy, 2);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 147456, 0, dw, dx, dy, pairs);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double flop32 = (double)nwg * 4 * 32 * 2.0 * pairs * 2.0 * 256 * 256;
+        printf("%-34s %8.2f ms  %7.1f fp32-equivalent TFLOP/s  (%.2fx of 142)\n", "6 products, hand-ordered + L2 pipe", ms,
+               flop32 / ms / 1e9, flop32 / ms / 1e9 / 142.0);
+    }
     {
         const int nwg = 256 * 4;
         auto kern = kp<true>;
