@@ -146,17 +146,17 @@ __global__ __launch_bounds__(256, 1) void kh(const unsigned* __restrict__ wsrc, 
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
-    f32x16 p0, p1;                                  // the previous tile's two partial accumulators
+    f32x16 p0;                                      // the previous tile's accumulator
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) p0[r] = 0.f;
     // one layer; `prev_out` receives the previous tile's fragments: for tile 0 that is the LAST tile of the layer
     // before (k-steps 14, 15 of `cur`, complete before this tile reaches k-step 14), otherwise tile-1 of `nxt`
     auto one_layer = [&](u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3]) {
 #pragma unroll
         for (int tile = 0; tile < 8; ++tile) {
-            f32x16 a0, a1;
+            f32x16 a0;                                  // one accumulator: dependent MFMAs issue back to back
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) a0[r] = 0.f;
             u32x4 wh = lds[((0 + tile * 5) % 48) * 64 + lane], wm = lds[((1 + tile * 5) % 48) * 64 + lane],
                   wl = lds[((2 + tile * 5) % 48) * 64 + lane];
 #pragma unroll
@@ -168,27 +168,27 @@ __global__ __launch_bounds__(256, 1) void kh(const unsigned* __restrict__ wsrc, 
                     nl = lds[((ks * 3 + 5 + tile * 5) % 48) * 64 + lane];
                 }
                 a0 = mm(wh, cur[ks][0], a0);
-                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wh, cur[ks][1], a0);
                 a0 = mm(wm, cur[ks][0], a0);
-                a1 = mm(wh, cur[ks][2], a1);
+                a0 = mm(wh, cur[ks][2], a0);
                 a0 = mm(wm, cur[ks][1], a0);
-                a1 = mm(wl, cur[ks][0], a1);
+                a0 = mm(wl, cur[ks][0], a0);
                 if (ks < 8) {                          // previous tile: registers 2ks, 2ks+1
-                    const float v0 = p0[2 * ks] + p1[2 * ks], v1 = p0[2 * ks + 1] + p1[2 * ks + 1];
+                    const float v0 = p0[2 * ks], v1 = p0[2 * ks + 1];
                     if (tile == 0) split_pair<ACT>(v0, v1, cur[14 + (ks >> 2)], ks & 3);
                     else split_pair<ACT>(v0, v1, nxt[2 * (tile - 1) + (ks >> 2)], ks & 3);
                 }
                 wh = nh; wm = nm; wl = nl;
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200);   // VALU / SALU / trans may move; MFMA, DS pinned
             }
-            p0 = a0; p1 = a1;
+            p0 = a0;
         }
     };
     for (int it = 0; it < pairs; ++it) {
         one_layer(A, B);
         one_layer(B, A);
     }
-    float s = p0[0] + p1[3];
+    float s = p0[0];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
@@ -219,18 +219,18 @@ __global__ __launch_bounds__(256, 1) void khp(const unsigned* __restrict__ wsrc,
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) A[ks][p][j] = pack_hi(xin[lane + 64 * ((ks + p + j) & 7)], xin[lane + 64 * ((ks * 3 + j) & 7) + 512]);
-    f32x16 p0, p1;                                  // the previous tile's two partial accumulators
+    f32x16 p0;                                      // the previous tile's accumulator
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p0[r] = 0.f; p1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) p0[r] = 0.f;
     // one layer; `prev_out` receives the previous tile's fragments: for tile 0 that is the LAST tile of the layer
     // before (k-steps 14, 15 of `cur`, complete before this tile reaches k-step 14), otherwise tile-1 of `nxt`
     auto one_layer = [&](auto lidx, u32x4 (&cur)[16][3], u32x4 (&nxt)[16][3]) {
         constexpr int LI = decltype(lidx)::value;
 #pragma unroll
         for (int tile = 0; tile < 8; ++tile) {
-            f32x16 a0, a1;
+            f32x16 a0;                                  // one accumulator: dependent MFMAs issue back to back
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) a0[r] = 0.f;
             constexpr int GT = LI * 8;                  // tiles done before this layer (mod 48 = 16 stored tiles x 3 buffers)
             const u32x4* lb = lds + ((GT + tile) % 3) * 3072;
             const u32x4* wn = w + (size_t)((LI * 8 + tile + 2) & 15) * 48 * 64 + (wv * 12) * 64;          // wave-uniform
@@ -244,26 +244,30 @@ __global__ __launch_bounds__(256, 1) void khp(const unsigned* __restrict__ wsrc,
                     nl = lb[(ks * 3 + 5) * 64 + lane];
                 }
                 if (ks == 0) {                                   // LDS-DMA of tile t+2 into the buffer tile t-1 used
+                    // inline asm (M0 = LDS base of the fragment, lanes land at base + 16*lane): as a builtin the DMA
+                    // makes hipcc spill ~2 KB per lane here
 #pragma unroll
-                    for (int fr = 0; fr < 12; ++fr)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(wn + fr * 64 + lane),
-                                                         (lptr_t)(lds + ((GT + tile + 2) % 3) * 3072 + (wv * 12 + fr) * 64), 16, 0, 0);
+                    for (int fr = 0; fr < 12; ++fr) {
+                        const unsigned ldsb = (((GT + tile + 2) % 3) * 3072 + (wv * 12 + fr) * 64) * 16;
+                        const u32x4* g = wn + fr * 64;
+                        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsb), "v"(lane * 16), "s"(g) : "m0");
+                    }
                 }
                 a0 = mm(wh, cur[ks][0], a0);
-                a1 = mm(wh, cur[ks][1], a1);
+                a0 = mm(wh, cur[ks][1], a0);
                 a0 = mm(wm, cur[ks][0], a0);
-                a1 = mm(wh, cur[ks][2], a1);
+                a0 = mm(wh, cur[ks][2], a0);
                 a0 = mm(wm, cur[ks][1], a0);
-                a1 = mm(wl, cur[ks][0], a1);
+                a0 = mm(wl, cur[ks][0], a0);
                 if (ks < 8) {                          // previous tile: registers 2ks, 2ks+1
-                    const float v0 = p0[2 * ks] + p1[2 * ks], v1 = p0[2 * ks + 1] + p1[2 * ks + 1];
+                    const float v0 = p0[2 * ks], v1 = p0[2 * ks + 1];
                     if (tile == 0) split_pair<ACT>(v0, v1, cur[14 + (ks >> 2)], ks & 3);
                     else split_pair<ACT>(v0, v1, nxt[2 * (tile - 1) + (ks >> 2)], ks & 3);
                 }
                 wh = nh; wm = nm; wl = nl;
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200);   // VALU / SALU / trans may move; MFMA, DS pinned
             }
-            p0 = a0; p1 = a1;
+            p0 = a0;
             __builtin_amdgcn_s_waitcnt(0x007c);            // vmcnt(12) lgkmcnt(0): all but the newest tile's DMA have landed
             __builtin_amdgcn_s_barrier();
         }
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void khp(const unsigned* __restrict__ wsrc,
         one_layer(std::integral_constant<int, 0>{}, A, B);
         one_layer(std::integral_constant<int, 1>{}, B, A);
     }
-    float s = p0[0] + p1[3];
+    float s = p0[0];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
