@@ -61,26 +61,124 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(sm, batch_cpu, opts, budget_s=20.0):
+def cpu_baseline(sm, batch_cpu, opts, budget_s=20.0, threads=None):
     """Oracle ("port") timed on the host: same workload on a bounded sample (chunks of 2048 samples
-    until `batch_cpu` samples or `budget_s` seconds, whichever comes first)."""
+    until `batch_cpu` samples or `budget_s` seconds, whichever comes first), on `threads` torch threads
+    (default: every core this process may use)."""
     from oracle import flowfusion_oracle as O
     sd = {k: v.detach().cpu() for k, v in sm.state_dict().items()}
     so = O.ScoreOracle(O.mlp_params_from_state_dict(sd, "model."), O.VP(), no_sigma=True)
-    cores = usable_cores()
+    cores = threads or usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     z = torch.randn(batch_cpu, DIM)
     so.sample_ode_from_base(z[:256], None, "rk4", {"step_size": opts["step_size"] * 10})   # warm-up
     outs, done = [], 0
     t0 = time.perf_counter()
+    chunk = 2048 if cores > 1 else 256
     while done < batch_cpu and (time.perf_counter() - t0 < budget_s or done == 0):
-        outs.append(so.sample_ode_from_base(z[done:done + 2048], None, "rk4", opts))
+        outs.append(so.sample_ode_from_base(z[done:done + chunk], None, "rk4", opts))
         done += outs[-1].shape[0]
     dt = time.perf_counter() - t0
     return torch.cat(outs), z[:done], {
         "value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
         "sample": f"{done} samples x 100 RK4 steps (same model and grid, torch fp32 CPU oracle, {dt:.1f} s)"}
+
+
+def _timed(fn, device):
+    """(result, wall seconds, HIP-event milliseconds) of one call, synchronised on both sides."""
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    r = fn()
+    e1.record()
+    torch.cuda.synchronize(device)
+    return r, time.perf_counter() - t0, e0.elapsed_time(e1)
+
+
+def _record(name, units, unit, wall_s, kernel, kernel_ms, flop, note):
+    ach = flop / (kernel_ms * 1e-3) / 1e12
+    return {"workload": name, "value": units / wall_s, "unit": unit, "wall_ms": 1e3 * wall_s, "kernel": kernel,
+            "kernel_ms": kernel_ms, "launches": note.get("launches", 1), "flop_algorithmic": flop,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS}, "dtype": "f32", **{k: v for k, v in note.items() if k != "launches"}}
+
+
+def extra_configs(device):
+    """BASELINE configs 3, 4 and 5 (and the reference's default exact-trace log_prob), ONE full-size call each
+    after a small warm-up call: `value` = units / wall clock of the public method (what a user sees, host work
+    included), `kernel_ms` = HIP events around the fused launch alone where the public method does host work
+    first (configs 3 / exact: the probe is drawn on the CPU like the reference, diffusion.py:701), else around
+    the call.  FLOPs are algorithmic: 2 x MACs of the Linear layers x evaluations x MFMA columns a sample needs
+    (1 state, +1 Hutchinson tangent, +D unit tangents)."""
+    from flowfusion_amd import _native
+    from flowfusion_amd import flow as Fm
+    from flowfusion_amd.diffusion import MLP, VESDE, ScoreModel
+    name_of = lambda net, mode: _native.lib().ff_kernel_name(net.plan(mode).kernel_id).decode()
+    out = []
+    g = torch.Generator(device=device).manual_seed(4321)
+    # --- config 3: same 16-dim model, log_prob with the Hutchinson divergence, 2^20 ------------------------------
+    sm = build_model(device)
+    sm.hutch = True
+    eps = float(sm.sde.epsilon)
+    opts = {"step_size": (1.0 - eps) / N_STEPS}
+    B = 1 << 20
+    x0 = torch.randn(B, DIM, device=device, generator=g) * 0.9
+    sm.log_prob(x0[:256], method="rk4", options=opts)
+    _, wall, _ = _timed(lambda: sm.log_prob(x0, method="rk4", options=opts), device)
+    net = sm._net()
+    tab = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, 1).to(device)
+    _, _, kms = _timed(lambda: net.integrate(x0, tab, 1, probe=sm.e), device)
+    out.append(_record("BASELINE configs[2]: 16-dim VP-SDE 4x256, log_prob, Hutchinson divergence, 100-step RK4, batch 2^20",
+                       B, "log-probs/s", wall, name_of(net, 1), kms, 2 * 2.0 * mac_per_eval(DIM, UNITS) * tab.shape[0] * B,
+                       {"note": "wall includes the reference's CPU draw of the probe (diffusion.py:701) and its upload"}))
+    # --- the reference's default divergence: exact trace (D unit tangents), 2^16 ---------------------------------
+    sm.hutch = False
+    Be = 1 << 16
+    sm.log_prob(x0[:64], method="rk4", options=opts)
+    _, wall, _ = _timed(lambda: sm.log_prob(x0[:Be].contiguous(), method="rk4", options=opts), device)
+    tab2 = sm._ode_table(torch.tensor([eps, 1.0]), "rk4", opts, 2).to(device)
+    xe = x0[:Be].contiguous()
+    _, _, kms = _timed(lambda: net.integrate(xe, tab2, 2), device)
+    from flowfusion_amd.fused import exact_trace_passes
+    passes = exact_trace_passes(DIM, net.plan(2).tile)
+    out.append(_record("16-dim VP-SDE 4x256, log_prob with the exact trace (reference default divergence), 100-step RK4, batch 2^16",
+                       Be, "log-probs/s", wall, name_of(net, 2), kms, (DIM + 1) * 2.0 * mac_per_eval(DIM, UNITS) * tab2.shape[0] * Be,
+                       {"launches": len(passes), "note": "kernel_ms sums the launches; columns carried: "
+                        + " + ".join(f"(1+{c})" for _, c in passes) + f" for {DIM}+1 needed"}))
+    del sm, net, x0, xe
+    # --- config 4: 64-dim flow matching, 5x512, 200 fixed Dormand-Prince steps, 2^22 / 8 GPUs = 2^19 per GPU ------
+    torch.manual_seed(0)
+    f = Fm.ODEFlow(64, [512] * 5).to(device).eval()
+    B4 = 1 << 19
+    xT = torch.randn(B4, 64, device=device, generator=g)
+    o4 = {"step_size": 1.0 / 200}
+    f.sample(xT[:64].contiguous(), method="dopri5_fixed", options=o4)
+    _, wall, kms = _timed(lambda: f.sample(xT, method="dopri5_fixed", options=o4), device)
+    mac4 = 65 * 512 + 4 * 512 * 512 + 512 * 64
+    out.append(_record("BASELINE configs[3]: 64-dim flow matching 5x512, 200-step fixed Dormand-Prince (1200 evals), "
+                       "per-GPU share 2^19 of 2^22", B4, "samples/s", wall, name_of(f._net(), 0), kms,
+                       2.0 * mac4 * 1200 * B4, {}))
+    del f, xT
+    # --- config 5: conditional 32-dim VE, 4x256, C = 8, 1000-step Euler-Maruyama, 2^20 ---------------------------
+    torch.manual_seed(0)
+    sm5 = ScoreModel(MLP(32, 8, EMB, UNITS), VESDE()).eval().to(device)
+    B5 = 1 << 20
+    cond = torch.randn(B5, 8, device=device, generator=g)
+    mac5 = mac_per_eval(32, UNITS, 8)
+    sm5.sample_sde((256, 32), conditional=cond[:256].contiguous(), steps=1000)
+    for kind, kw, note in (("torch noise (the reference's random stream; 1 GiB noise buffers filled on a side stream)", {}, "torch"),
+                           ("in-kernel counter-based noise, one launch", {"noise": "philox", "seed": 1}, "philox")):
+        sm5.sample_sde((256, 32), conditional=cond[:256].contiguous(), steps=8, **kw)
+        _, wall, kms = _timed(lambda: sm5.sample_sde((B5, 32), conditional=cond, steps=1000, **kw), device)
+        out.append(_record(f"BASELINE configs[4]: conditional 32-dim VE-SDE 4x256 (8 conditionals), 1000-step Euler-Maruyama, "
+                           f"batch 2^20, {kind}", B5, "samples/s", wall, name_of(sm5._net(), 0), kms,
+                           2.0 * mac5 * 1000 * B5,
+                           {"launches": 1 if note == "philox" else -(-1000 // max(1, (1 << 28) // (B5 * 32))),
+                            "note": "wall and kernel_ms bracket the whole public call (prior draw on the host like the "
+                                    "reference, noise kernels, launches)"}))
+    return out
 
 
 def main():
@@ -92,6 +190,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32768, help="samples for the CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="skip the one-launch timings of BASELINE configs 3, 4, 5 (N = 1 only)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -137,6 +237,8 @@ def main():
             events[1].record()
         if world > 1:      # the single collective of the path: all shards meet on every rank
             dist.all_gather_into_tensor(gathered, x if args.backend == "nccl" else x.cpu())
+            if events is not None:
+                events[2].record()
         return x
 
     def barrier():
@@ -147,7 +249,7 @@ def main():
     for _ in range(args.warmup):
         x = step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     net = sm._net()
     from flowfusion_amd import _native
     kernel_name = _native.lib().ff_kernel_name(net.plan(0).kernel_id).decode()
@@ -164,8 +266,17 @@ def main():
         elapsed = float(tmax.item())
 
     # per-launch kernel time of the timed steps themselves
-    kernel_ms = sorted(s.elapsed_time(e) for s, e in ev)
+    kernel_ms = sorted(s.elapsed_time(e) for s, e, _ in ev)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    per_rank = None
+    if world > 1:
+        # what each rank spent in its kernel and in the collective (gloo rehearsal: the collective runs on the host
+        # after a device-to-host copy, the events then only bracket that copy's enqueue)
+        gather_ms_avg = sum(e.elapsed_time(g) for _, e, g in ev) / len(ev) if args.backend == "nccl" else float("nan")
+        mine = torch.tensor([kernel_ms_avg, gather_ms_avg], device=gather_dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms_avg": [float(t[0]) for t in allr], "allgather_ms_avg": [float(t[1]) for t in allr]}
 
     if rank == 0:
         print(f"[bench] timed region {elapsed:.3f} s, kernel avg {kernel_ms_avg:.1f} ms", file=sys.stderr, flush=True)
@@ -198,11 +309,19 @@ def main():
                          "algorithmic_hbm_GBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        # `traffic` cannot be measured by this process (PMC counters need a rocprofv3 pass of their own): it is the
+        # committed result of tools/profile_round.sh for this kernel at this batch, and says so
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
-        if traffic_file.exists():      # PMC measurement of this kernel at this batch (profiles/r01), per launch
+        if traffic_file.exists():
             tf = json.loads(traffic_file.read_text())
             if tf.get("batch") == B and kernel_name.split("_m")[-1].split("_")[0] in tf.get("kernel", ""):
                 out["roofline"]["traffic"] = tf.get("bytes_per_launch")
+                out["roofline"]["traffic_source"] = {
+                    "file": "profiles/hbm_traffic.json", "from": tf.get("source"), "commit": tf.get("commit"),
+                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
+                            "not measured by this run"}
         if args.cpu_batch > 0 and world == 1:      # CPU baseline and oracle parity: rank 0 of the 1-GPU run only
             ref, zc, cb = cpu_baseline(sm, args.cpu_batch, opts)
             out["cpu_baseline"] = cb
@@ -221,6 +340,12 @@ def main():
             lp = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
             lp_ref = so.log_prob(xq, None, "rk4", opts, "hutch", sm.e.cpu())
             out["log_prob_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+            sm.hutch = False
+            _, _, cb1 = cpu_baseline(sm, 2048, opts, budget_s=10.0, threads=1)
+            out["cpu_baseline_1thread"] = cb1
+            torch.set_num_threads(usable_cores())
+        if args.extras and world == 1:
+            out["extra_configs"] = extra_configs(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

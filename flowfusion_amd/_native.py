@@ -41,7 +41,7 @@ class PlanStruct(ctypes.Structure):
         ("tile", ctypes.c_int32),
         ("activation", ctypes.c_int32),
         ("act_param", ctypes.c_float * 2),
-        ("reserved", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
     ]
 
 
@@ -78,6 +78,19 @@ class OdeArgs(ctypes.Structure):
         ("jac_out", ctypes.c_void_p),
     ]
 
+
+class CombineArgs(ctypes.Structure):      # ff_combine_args
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("k", ctypes.c_void_p * 7),
+        ("coef", ctypes.c_float * 7),
+        ("x_coef", ctypes.c_float),
+        ("out", ctypes.c_void_p),
+        ("n", ctypes.c_int64),
+    ]
+
+
+PRIOR_NOISE_INDEX = 0xFFFFFFFF     # FF_PRIOR_NOISE_INDEX
 
 _lib = None
 
@@ -119,6 +132,11 @@ def lib() -> ctypes.CDLL:
     L.ff_mlp_samples_per_workgroup.restype = ctypes.c_int
     L.ff_mlp_samples_per_workgroup.argtypes = [ctypes.POINTER(PlanStruct), ctypes.c_int]
     L.ff_last_hip_error.restype = ctypes.c_int
+    L.ff_normal_fill.restype = ctypes.c_int
+    L.ff_normal_fill.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64,
+                                 ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p]
+    L.ff_stage_combine.restype = ctypes.c_int
+    L.ff_stage_combine.argtypes = [ctypes.POINTER(CombineArgs), ctypes.c_void_p]
     _lib = L
     return L
 
@@ -165,6 +183,59 @@ def pack_weights(plan: PlanStruct, weights: List[torch.Tensor], biases: List[Opt
 
 def samples_per_workgroup(plan: PlanStruct, mode: int) -> int:
     return int(lib().ff_mlp_samples_per_workgroup(ctypes.byref(plan), mode))
+
+
+def normal_fill(batch: int, dim: int, seed: int, sample_offset: int, device, noise_index: int = PRIOR_NOISE_INDEX,
+                scale: float = 1.0) -> torch.Tensor:
+    """ff_normal_fill: [batch, dim] normals of the counter-based stream for global rows
+    sample_offset .. sample_offset + batch - 1 (the prior draw of the sharded Euler-Maruyama sampler)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("flowfusion_amd: ff_normal_fill fills device memory (there is no CPU path)")
+    out = torch.empty(batch, dim, dtype=torch.float32, device=device)
+    if batch == 0:
+        return out
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        rc = lib().ff_normal_fill(out.data_ptr(), batch, dim, seed & 0xFFFFFFFFFFFFFFFF, sample_offset,
+                                  noise_index & 0xFFFFFFFF, float(scale), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_normal_fill")
+    return out
+
+
+def stage_combine(out: torch.Tensor, x: Optional[torch.Tensor], ks, coefs, x_coef: float = 1.0) -> torch.Tensor:
+    """ff_stage_combine: out = x_coef * x + sum_s coefs[s] * ks[s] in one pass (flat fp32 device tensors of
+    equal numel; `out` may alias an input).  Terms with a zero coefficient are not read."""
+    if not out.is_cuda:
+        raise RuntimeError("flowfusion_amd: ff_stage_combine works on device memory (there is no CPU path)")
+    dev = out.device
+    a = CombineArgs()
+    n = out.numel()
+    a.out = _chk(out, "out", dev)
+    a.x = _chk(x, "x", dev)
+    if x is not None and x.numel() != n:
+        raise RuntimeError("stage_combine: x and out differ in size")
+    if len(ks) > 7 or len(ks) != len(coefs):
+        raise RuntimeError("stage_combine: at most FF_MAX_SLOTS = 7 terms, one coefficient each")
+    for s, (k, c) in enumerate(zip(ks, coefs)):
+        c = float(c)
+        if k is None or c == 0.0:
+            continue
+        if k.numel() != n:
+            raise RuntimeError("stage_combine: term and out differ in size")
+        a.k[s] = _chk(k, f"k[{s}]", dev)
+        a.coef[s] = c
+    a.x_coef = float(x_coef)
+    a.n = n
+    if n == 0:
+        return out
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().ff_stage_combine(ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_stage_combine")
+    return out
 
 
 _PLAN_WORDS = ctypes.sizeof(PlanStruct) // 4

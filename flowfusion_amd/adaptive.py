@@ -74,8 +74,14 @@ def _onehot(i):
 class Dopri5:
     """Batch-global adaptive Dormand-Prince over an increasing solver-time span [t0, t1]."""
 
-    def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None):
+    def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None,
+                 norm_only=()):
+        """``norm_only``: components the reference carries in the tuple state with a zero derivative (the raw
+        ``conditional`` of ConditionalODEFlow, flow.py:779-796, 855-881).  Under the mixed norm they can only
+        matter where the state itself is measured -- d0 of the initial step; their derivative and error
+        estimate are identically zero."""
         opts = dict(options or {})
+        self.norm_only = [c for c in norm_only if c is not None and c.numel() > 0]
         self.step = step
         self.has_lp = has_lp
         self.rtol = float(rtol)
@@ -123,7 +129,8 @@ class Dopri5:
         scale = [self.atol + p.abs() * self.rtol for p in (y, lp) if p is not None]
         ys = [p for p in (y, lp) if p is not None]
         fs = [p for p in (f0, fl0) if p is not None]
-        d0 = _mixed_norm([a / s for a, s in zip(ys, scale)])
+        d0 = _mixed_norm([a / s for a, s in zip(ys, scale)] +
+                         [c / (self.atol + c.abs() * self.rtol) for c in self.norm_only])
         d1 = _mixed_norm([a / s for a, s in zip(fs, scale)])
         h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
         h0 = float(_f32(abs(h0)))

@@ -45,6 +45,14 @@ extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidde
 extern "C" int ff_mlp_plan_act(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
                                int activation, const float* act_param, ff_mlp_plan_t* plan)
 {
+    return ff_mlp_plan_prec(dim, cond_dim, n_hidden, hidden_widths, mode, activation, act_param, FF_PREC_F32, plan);
+}
+
+extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                                int activation, const float* act_param, int precision, ff_mlp_plan_t* plan)
+{
+    if (precision != FF_PREC_F32 && precision != FF_PREC_BF16X3) return FF_ERR_BADARG;
+    if (precision == FF_PREC_BF16X3) return FF_ERR_UNSUPPORTED;
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
     // FF_ANY_ACT=1 sends SiLU networks to the run-time-activation kernels as well (A/B tests)
@@ -96,6 +104,7 @@ static bool plan_ok(const ff_mlp_plan_t* p)
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
     const int per_reg = 64 / k.tile;
     return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
+           p->precision == FF_PREC_F32 &&
            p->activation >= 0 && p->activation < FF_ACT_COUNT && (p->activation == FF_ACT_SILU || k.any_act) &&
            p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
 }

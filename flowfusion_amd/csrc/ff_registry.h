@@ -5,6 +5,8 @@
 
 namespace ff {
 
+constexpr int kMaxDevices = 64;   // launchers keep one "attribute set" flag per device of the process
+
 typedef int (*LaunchFn)(const KernelArgs* args, unsigned grid, unsigned lds_bytes, hipStream_t stream);
 
 struct KernelEntry {

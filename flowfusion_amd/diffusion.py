@@ -256,7 +256,7 @@ class ScoreModel(nn.Module):
                 "the fused gfx950 path needs a flowfusion MLP score network "
                 f"(NN/W/pi attributes); got {type(m).__name__}")
         act = activation_spec(m.activation)
-        if self._fused is None or self._fused.linears[0] is not m.NN[0] or self._fused.act != act:
+        if self._fused is None or not self._fused.serves(list(m.NN), act):
             E = 2 * m.W.numel()
             self._fused = FusedNet(list(m.NN), m.n_dimensions, m.n_conditionals, x_col0=E,
                                    c_col0=E + m.n_dimensions, act=act)
@@ -307,11 +307,15 @@ class ScoreModel(nn.Module):
         a, b, c1, _ = self._schedule(plan.t_eval, "ode")
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
 
-    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None):
+    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, **affine):
         """odeint(self, state, t_span, method=, atol=, rtol=, options=) on the fused kernels:
-        fixed-grid methods as one launch, ``dopri5`` as one launch per attempted step."""
+        fixed-grid methods as one launch, ``dopri5`` as one launch per attempted step.  ``affine``
+        (in_shift / in_scale / out_scale / out_shift, the PopulationModel wrappers' pre- and post-processing)
+        rides in the kernel's prologue / epilogue on fixed grids and is applied around the adaptive loop."""
         net = self._net()
         if method == "dopri5":
+            if affine.get("in_shift") is not None:
+                x = (x - affine["in_shift"]) / affine["in_scale"]
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
             host = self._schedule_inputs()
@@ -322,11 +326,13 @@ class ScoreModel(nn.Module):
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
+            if affine.get("out_scale") is not None:
+                y = y * affine["out_scale"] + affine["out_shift"]
             return y, lp
         key = ("score-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode,
                self.no_sigma, self._schedule_key())
         table = net.cached_table(key, x.device, lambda: self._ode_table(t_span, method, options, mode))
-        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe)
+        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
         return y, (lp if mode != MODE_STATE else None)
 
     def _schedule_key(self):
@@ -340,34 +346,41 @@ class ScoreModel(nn.Module):
         return tuple(vals) + (m.W.data_ptr(), m.W._version)
 
     @torch.no_grad()
-    def sample_sde(self, shape, conditional=None, steps=100, *, noise="torch", seed=None, sample_offset=0):
+    def sample_sde(self, shape, conditional=None, steps=100, *, noise="torch", seed=None, sample_offset=0,
+                   progress=None, progress_every=None):
         """Euler-Maruyama sampling of the reverse SDE; returns the last *mean* state, like the
         reference (diffusion.py:510-563).  By default random numbers are drawn exactly as the reference
         draws them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
-        ``torch.manual_seed`` reproduces the reference's stream on that device.
+        ``torch.manual_seed`` reproduces the reference's stream on that device.  If a step produces a NaN the
+        reference prints a message, stops and returns that step's mean (:560-563); so does this method (the
+        step is located after the fact, by re-running a prefix of the launch that reported it).
 
-        Extension: ``noise="philox"`` draws the per-step normals inside the kernel (counter-based, keyed by
+        Extensions: ``noise="philox"`` draws the per-step normals inside the kernel (counter-based, keyed by
         ``seed`` and the global sample index ``sample_offset + row``; include/flowfusion_amd.h): no noise
         buffers, no random-number kernels, and the result for a sample does not depend on how the batch is
         split over launches or GPUs (``flowfusion_amd.distributed.sample_sde_sharded``).  ``seed=None``
-        takes one from torch's default generator, so ``torch.manual_seed`` still fixes the run."""
+        takes one from torch's default generator, so ``torch.manual_seed`` still fixes the run.
+        ``progress(done, total)`` is called after every ``progress_every`` steps (default: a tenth of the
+        run) -- the reference's tqdm bar (:543-547) at launch granularity instead of three host syncs per
+        step."""
         batch, *dims = shape
         dev = next(self.model.parameters()).device
         x = self.sde.prior(dims).sample([batch]).to(dev)
+        kw = dict(progress=progress, progress_every=progress_every)
         if noise == "torch":
-            return self._sample_sde_from(x, lambda like: torch.randn_like(like), conditional, steps)
+            return self._sample_sde_from(x, lambda like: torch.randn_like(like), conditional, steps, **kw)
         if noise != "philox":
             raise ValueError(f"noise={noise!r}: expected 'torch' or 'philox'")
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        return self._sample_sde_from(x, None, conditional, steps, rng=(int(seed), int(sample_offset)))
+        return self._sample_sde_from(x, None, conditional, steps, rng=(int(seed), int(sample_offset)), **kw)
 
     @torch.no_grad()
-    def _sample_sde_from(self, x, draw, conditional=None, steps=100, rng=None):
+    def _sample_sde_from(self, x, draw, conditional=None, steps=100, rng=None, progress=None, progress_every=None):
         """The Euler-Maruyama loop proper: ``x`` is the prior draw, ``draw(like)`` supplies the i-th
         standard-normal slab (tests inject the reference's captured stream here); with
-        ``rng = (seed, global index of row 0)`` the kernel draws the normals itself and the whole loop is one
-        launch."""
+        ``rng = (seed, global index of row 0)`` the kernel draws the normals itself.  The steps run in as few
+        launches as the noise memory and the progress granularity allow (one, normally)."""
         net = self._net()
         if x.dim() != 2:
             raise NotImplementedError("sample_sde: only [batch, dim] states are supported")
@@ -381,72 +394,96 @@ class ScoreModel(nn.Module):
             raise RuntimeError("sample_sde: T < epsilon, no step to take")
         a, b, c1, g = self._schedule(ts, "sde")
         gn = g * (-dt) ** (1.0 / 2.0)                 # g * sqrt(-dt)  (:554-558)
-        flags = torch.full((n,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32)
-        flags[-1] = solvers.FLAG_STEP_END             # the returned state is x_mean of the last step (:563)
         cout = torch.zeros(n, 8)
         cout[:, 0] = dt                               # x_mean = x + f dt  (:557)
         zeros8 = torch.zeros(n, 8)
         slot = torch.zeros(n, dtype=torch.int32)
-        if rng is not None:
-            full = solvers.EvalPlan(t_eval=ts, sign=1.0, slot=slot, flags=flags, cin=zeros8, cout=cout, n_steps=n)
-            table = solvers.build_table(full, a, b, c1, net.width(MODE_STATE), gn=gn, noise_idx=torch.arange(n)).to(dev)
-            x, _, status = net.integrate(x, table, MODE_STATE, cond=conditional,
-                                         rng=(rng[0] & 0x7FFFFFFFFFFFFFFF, rng[1], 0))
-            if int(status.item()) & 1:
-                print("Diffusion is not stable, NaN were produced. Stopped sampling.")
-            return x
-        # Noise slabs are drawn per step, in order, chunked over steps to bound memory.  The draws
-        # of chunk c+1 are enqueued on a side stream while the kernel integrates chunk c (two
-        # buffers), so the random-number kernels stay off the critical path; the host-side generator
-        # is advanced in the same order either way, so the stream of numbers is unchanged.
-        per_step = max(batch * x.shape[1], 1)
-        chunk = max(1, min(n, (1 << 28) // per_step))
-        bounds = [(s0, min(n, s0 + chunk)) for s0 in range(0, n, chunk)]
-        tables = []
-        for start, stop in bounds:
-            sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=slot[start:stop], flags=flags[start:stop],
+        width = net.width(MODE_STATE)
+
+        def table(start, stop, mean_last):
+            """Rows of steps [start, stop); with `mean_last` the last one returns x_mean (no noise added, :563)."""
+            flags = torch.full((stop - start,), solvers.FLAG_STEP_END | solvers.FLAG_NOISE, dtype=torch.int32)
+            if mean_last:
+                flags[-1] = solvers.FLAG_STEP_END
+            sub = solvers.EvalPlan(t_eval=ts[start:stop], sign=1.0, slot=slot[start:stop], flags=flags,
                                    cin=zeros8[start:stop], cout=cout[start:stop], n_steps=stop - start)
-            tables.append(solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], net.width(MODE_STATE),
-                                              gn=gn[start:stop], noise_idx=torch.arange(stop - start)).to(dev))
-        bufs = [torch.empty(min(chunk, n), batch, x.shape[1], device=dev, dtype=torch.float32)
-                for _ in range(min(2, len(bounds)))]
-        if len(bounds) == 1:
-            # everything fits one buffer: nothing to overlap, draw on the current stream
-            for i in range(n):
-                bufs[0][i] = draw(x)
-            x, _, status = net.integrate(x, tables[0], MODE_STATE, cond=conditional, noise=bufs[0][:n])
-            if int(status.item()) & 1:
-                print("Diffusion is not stable, NaN were produced. Stopped sampling.")
-            return x
-        main = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
+            return solvers.build_table(sub, a[start:stop], b[start:stop], c1[start:stop], width,
+                                       gn=gn[start:stop], noise_idx=torch.arange(stop - start)).to(dev)
+
+        def launch(x_in, start, stop, mean_last, buf):
+            if rng is not None:
+                return net.integrate(x_in, table(start, stop, mean_last), MODE_STATE, cond=conditional,
+                                     rng=(rng[0] & 0x7FFFFFFFFFFFFFFF, rng[1], start))
+            return net.integrate(x_in, table(start, stop, mean_last), MODE_STATE, cond=conditional,
+                                 noise=buf[: stop - start])
+
+        def first_nan_mean(x_in, start, stop, buf):
+            """A launch over steps [start, stop) reported NaN: the reference would have stopped at the first
+            step whose state x (noise included, :558-560) has one and returned that step's mean.  NaN is
+            absorbing, so bisect on the number of full steps (each probe = one launch of a prefix), then
+            re-run that prefix with a mean-only last row."""
+            lo, hi = 1, stop - start                  # smallest m with a NaN in x after m steps
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if int(launch(x_in, start, start + mid, False, buf)[2].item()) & 1:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            return launch(x_in, start, start + lo, True, buf)[0]
+
+        # chunk boundaries: noise slabs are drawn per step, in order, at most 2^28 floats (1 GiB) per buffer;
+        # a progress callback adds boundaries of its own
+        per_step = max(batch * x.shape[1], 1)
+        chunk = n if rng is not None else max(1, min(n, (1 << 28) // per_step))
+        if progress is not None:
+            every = int(progress_every) if progress_every else max(1, n // 10)
+            chunk = max(1, min(chunk, every))
+        bounds = [(s0, min(n, s0 + chunk)) for s0 in range(0, n, chunk)]
+        bufs = [] if rng is not None else [
+            torch.empty(min(chunk, n), batch, x.shape[1], device=dev, dtype=torch.float32)
+            for _ in range(min(2, len(bounds)))]
+        # The draws of chunk c+1 are enqueued on a side stream while the kernel integrates chunk c (two
+        # buffers), so the random-number kernels stay off the critical path; the host-side generator is
+        # advanced in the same order either way, so the stream of numbers is unchanged.
+        overlap = rng is None and len(bounds) > 1
+        main = torch.cuda.current_stream(dev) if x.is_cuda else None
+        side = torch.cuda.Stream(device=dev) if overlap else None
         ready = [None] * len(bounds)
         freed = [None] * len(bufs)
 
         def fill(c):
             start, stop = bounds[c]
             buf = bufs[c % len(bufs)]
+            if not overlap:
+                for i in range(stop - start):                   # one draw per executed step, the last included (:554)
+                    buf[i] = draw(x)
+                return
             with torch.cuda.stream(side):
                 if freed[c % len(bufs)] is not None:
                     side.wait_event(freed[c % len(bufs)])       # the kernel that read this buffer is done
                 else:
                     side.wait_stream(main)
-                for i in range(stop - start):                   # one draw per executed step, the last included (:554)
+                for i in range(stop - start):
                     buf[i] = draw(x)
                 ready[c] = side.record_event()
 
-        fill(0)
-        status_any = None
+        if rng is None:
+            fill(0)
         for c, (start, stop) in enumerate(bounds):
-            if c + 1 < len(bounds):
+            if overlap and c + 1 < len(bounds):
                 fill(c + 1)
-            main.wait_event(ready[c])
-            buf = bufs[c % len(bufs)]
-            x, _, status = net.integrate(x, tables[c], MODE_STATE, cond=conditional, noise=buf[: stop - start])
-            freed[c % len(bufs)] = main.record_event()
-            status_any = status if status_any is None else (status_any | status)
-        if int(status_any.item()) & 1:
-            print("Diffusion is not stable, NaN were produced. Stopped sampling.")
+            if overlap:
+                main.wait_event(ready[c])
+            buf = bufs[c % len(bufs)] if bufs else None
+            x_in = x
+            x, _, status = launch(x_in, start, stop, stop == n, buf)
+            if overlap:
+                freed[c % len(bufs)] = main.record_event()
+            if int(status.item()) & 1:
+                print("Diffusion is not stable, NaN were produced. Stopped sampling.")
+                return first_nan_mean(x_in, start, stop, buf)
+            if progress is not None:
+                progress(stop, n)
         return x
 
     def sample_ode_from_base(self, base_samples, conditional=None, atol=1e-4, rtol=1e-4,
@@ -454,24 +491,38 @@ class ScoreModel(nn.Module):
         """Probability-flow ODE from t=1 down to epsilon; returns ``(samples, [])`` like the
         reference (diffusion.py:566-640).  ``atol``/``rtol`` are accepted for signature
         compatibility and unused by the fixed-grid methods."""
+        return self._sample_ode(base_samples, conditional, atol, rtol, method, options), []
+
+    def _sample_ode(self, base_samples, conditional, atol, rtol, method, options, out_scale=None, out_shift=None):
+        """sample_ode_from_base proper; ``x * out_scale + out_shift`` (PopulationModel*.forward,
+        diffusion.py:1575-1585, 1772-1784) is applied by the kernel's epilogue."""
         self._check_inputs(base_samples, "sample_ode_from_base")
-        net = self._net()
+        self._net()
         z = base_samples * self.sde.sigma_max if hasattr(self.sde, "sigma_max") else base_samples
         self.prob = False
         self.conditional = conditional
         t_span = torch.tensor([1.0, float(self.sde.epsilon)], dtype=torch.float32)
-        x, _ = self._solve(z, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional)
-        return x, []
+        x, _ = self._solve(z, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional,
+                           out_scale=out_scale, out_shift=out_shift)
+        return x
 
     @torch.no_grad()
     def solve_odes_forward(self, x0_samples, conditional=None, atol=1e-5, rtol=1e-5,
                            method="dopri5", options=None):
         """Probability-flow ODE from epsilon up to t=1 with the divergence integrated alongside;
         returns ``(xT, delta_logp[B,1])`` (reference: diffusion.py:642-754)."""
-        net = self._net()
+        return self._solve_forward(x0_samples, conditional, atol, rtol, method, options)
+
+    @torch.no_grad()
+    def _solve_forward(self, x0_samples, conditional, atol, rtol, method, options, in_shift=None, in_scale=None):
+        """solve_odes_forward proper; ``(x - in_shift) / in_scale`` (PopulationModel*.log_prob,
+        diffusion.py:1633, 1837) is applied by the kernel's prologue."""
+        self._net()
         self.prob = True
         self.conditional = conditional
         if (self.hutchpp or self.xtrace) and not self.hutch:
+            if in_shift is not None:
+                x0_samples = (x0_samples - in_shift) / in_scale
             return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options)
         probe = None
         mode = MODE_EXACT
@@ -481,7 +532,8 @@ class ScoreModel(nn.Module):
             probe = self.e
             mode = MODE_HUTCH
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
-        xT, dlogp = self._solve(x0_samples, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe)
+        xT, dlogp = self._solve(x0_samples, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe,
+                                in_shift=in_shift, in_scale=in_scale)
         return xT, dlogp.view(-1, 1)
 
     def _solve_with_estimator(self, x0, conditional, atol, rtol, method, options):
@@ -540,9 +592,8 @@ class PopulationModelDiffusion(nn.Module):
         self.options = options
 
     def forward(self, base_samples):
-        x, _ = self.score_model.sample_ode_from_base(base_samples, method=self.method, atol=1e-5, rtol=1e-5,
-                                                     options=self.options)
-        return x * self.scale + self.shift
+        return self.score_model._sample_ode(base_samples, None, 1e-5, 1e-5, self.method, self.options,
+                                            out_scale=self.scale, out_shift=self.shift)
 
     def sample_sde(self, shape, steps=100):
         # the reference ignores `steps` here and always takes 100 (diffusion.py:1608)
@@ -550,8 +601,8 @@ class PopulationModelDiffusion(nn.Module):
 
     def log_prob(self, x, atol=1e-5, rtol=1e-5):
         # the reference does not forward self.method here: the solver default applies (diffusion.py:1633-1635)
-        xT, lp = self.score_model.solve_odes_forward((x - self.shift) / self.scale, atol=atol, rtol=rtol,
-                                                     options=self.options)
+        xT, lp = self.score_model._solve_forward(x, None, atol, rtol, "dopri5", self.options,
+                                                 in_shift=self.shift, in_scale=self.scale)
         return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), 1, keepdim=True)
 
 
@@ -576,15 +627,13 @@ class PopulationModelDiffusionConditional(nn.Module):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
     def forward(self, base_samples, conditional=None):
-        x, _ = self.score_model.sample_ode_from_base(base_samples, conditional=self._cond(conditional),
-                                                     method=self.method, atol=1e-5, rtol=1e-5, options=self.options)
-        return x * self.scale + self.shift
+        return self.score_model._sample_ode(base_samples, self._cond(conditional), 1e-5, 1e-5, self.method,
+                                            self.options, out_scale=self.scale, out_shift=self.shift)
 
     def sample_sde(self, shape, conditional=None, steps=100):
         return self.score_model.sample_sde(shape, conditional=self._cond(conditional), steps=100) * self.scale + self.shift
 
     def log_prob(self, x, conditional=None, atol=1e-5, rtol=1e-5):
-        xT, lp = self.score_model.solve_odes_forward((x - self.shift) / self.scale,
-                                                     conditional=self._cond(conditional), atol=atol, rtol=rtol,
-                                                     options=self.options)
+        xT, lp = self.score_model._solve_forward(x, self._cond(conditional), atol, rtol, "dopri5", self.options,
+                                                 in_shift=self.shift, in_scale=self.scale)
         return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), 1, keepdim=True)

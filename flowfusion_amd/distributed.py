@@ -68,20 +68,22 @@ def run_sharded(fn: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch
 def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] = None, steps: int = 100,
                        seed: int = 0, group=None, gather: bool = True):
     """Euler-Maruyama sampling (``ScoreModel.sample_sde``) of a [B, dim] batch over all ranks, with the
-    same result for any number of ranks: every rank draws the prior of the whole batch from the same
-    seeded generator and keeps its rows, and the per-step noise is the kernel's counter-based stream
-    keyed by ``seed`` and the GLOBAL row index (``noise="philox"``).  One all-gather at the end."""
+    same result for any number of ranks: both the prior draw and the per-step noise come from the library's
+    counter-based stream keyed by ``seed`` and the GLOBAL row index (prior: ``ff_normal_fill`` with the reserved
+    noise index; steps: ``noise="philox"``), so a rank only ever touches its own rows.  One all-gather at the
+    end."""
+    from . import _native
     batch, *dims = shape
+    if len(dims) != 1:
+        raise NotImplementedError("sample_sde_sharded: only [batch, dim] states are supported")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(batch, world, rank)
     dev = next(score_model.model.parameters()).device
-    gen = torch.Generator(device=dev).manual_seed(int(seed))
-    # the prior is Normal(0, scale) (diffusion.py:1003, 1093): draw unit normals for the whole batch from the
-    # seeded generator (one pass, the same numbers on every rank) and scale them the way the prior would
-    unit = torch.randn((batch, *dims), generator=gen, device=dev)
-    scale = score_model.sde.prior(dims).scale
-    x = (unit[lo:hi] * scale.to(dev)).contiguous()
+    # the prior is Normal(0, scale) (diffusion.py:1003, 1093)
+    sde = score_model.sde
+    scale = float(sde.sigma_max) if hasattr(sde, "sigma_max") else 1.0
+    x = _native.normal_fill(hi - lo, dims[0], int(seed), lo, dev, scale=scale)
     cond = None if conditional is None else conditional[lo:hi].contiguous()
     local = score_model._sample_sde_from(x, None, cond, steps, rng=(int(seed), lo))
     if not gather:

@@ -49,7 +49,7 @@ class _FlowBase(nn.Module):
         act = next(iter(specs))
         lin = self._linears()
         cached = getattr(self, "_fused", None)
-        if cached is None or cached.linears[0] is not lin[0] or cached.act != act:
+        if cached is None or not cached.serves(lin, act):
             D = self.target_dimension
             C = getattr(self, "conditional_dimension", 0)
             # first-layer columns: [x (D) | t (1) | cond (C)]
@@ -74,7 +74,7 @@ class _FlowBase(nn.Module):
     def _norm_cond(self, conditional):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
-    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, **affine):
+    def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, raw_cond=None, **affine):
         net = self._net()
         if method == "dopri5":
             if any(v is not None for v in affine.values()):
@@ -83,7 +83,9 @@ class _FlowBase(nn.Module):
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
             first = net.first_layer_cpu()
             step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
-            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options)
+            # the reference keeps the raw conditional in the solver state (flow.py:779-796, 855-881)
+            extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
+            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
@@ -94,25 +96,26 @@ class _FlowBase(nn.Module):
         y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
         return y, (lp if mode != MODE_STATE else None)
 
-    def _fused_sample(self, xT, conditional, method, options, atol, rtol):
+    def _fused_sample(self, xT, conditional, method, options, atol, rtol, raw_cond=None):
         if torch.is_grad_enabled() and xT.requires_grad:
             raise NotImplementedError("gradients through the fused solve are not available; detach the input")
         method = _DEFAULT_SAMPLE_METHOD if method is None else method
         t_span = torch.tensor([1.0, 0.0], dtype=torch.float32)
         if method == "dopri5":
-            x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional)
+            x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional, raw_cond=raw_cond)
             return x * self.target_scale + self.target_shift
         x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional,
                            out_scale=self.target_scale, out_shift=self.target_shift)
         return x
 
-    def _fused_forward(self, x, conditional, method, options, hutchinson, atol, rtol):
+    def _fused_forward(self, x, conditional, method, options, hutchinson, atol, rtol, raw_cond=None):
         t_span = torch.tensor([0.0, 1.0], dtype=torch.float32)
         mode, probe = MODE_EXACT, None
         if hutchinson:
             mode = MODE_HUTCH
             probe = torch.sign(torch.randn(x.shape)).to(x.device)
-        xT, logj = self._solve(x, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe)
+        xT, logj = self._solve(x, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe,
+                               raw_cond=raw_cond)
         return xT, logj.view(-1, 1)
 
 
@@ -229,14 +232,15 @@ class ConditionalODEFlow(_FlowBase):
         if gradients:
             raise NotImplementedError("sample(gradients=True) uses odeint_adjoint in the reference "
                                       "(flow.py:779-788); differentiable solves are out of scope")
-        return self._fused_sample(xT, self._norm_cond(conditional), method, options, atol, rtol)
+        return self._fused_sample(xT, self._norm_cond(conditional), method, options, atol, rtol, raw_cond=conditional)
 
     def solve_ode_forward(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5,
                           method: str = "dopri5", options: Optional[dict] = None, adjoint: bool = False,
                           hutchinson: bool = False):
         if adjoint:
             raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
-        return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson, atol, rtol)
+        return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson, atol, rtol,
+                                   raw_cond=conditional)
 
     def log_prob(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
                  options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):

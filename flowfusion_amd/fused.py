@@ -88,8 +88,16 @@ class FusedNet:
             if l.bias is None:
                 raise NotImplementedError("Linear layers without bias are not supported")
         self._plans = {}
-        self._wpack = None          # (key, device tensor)
+        self._wpack = {}            # layout key -> (parameter versions, packed device tensor)
         self._tables = {}           # small cache of evaluation tables already on the device
+
+    def serves(self, linears, act) -> bool:
+        """True if this view was built from exactly these Linear modules (identity, in order) and this
+        activation.  The front ends rebuild the view otherwise: a layer replaced after the first solve
+        (``model.NN[2] = nn.Linear(..)``) must not keep integrating with the old weights."""
+        act = (int(act[0]), float(act[1]), float(act[2]))
+        return (self.act == act and len(linears) == len(self.linears)
+                and all(a is b for a, b in zip(linears, self.linears)))
 
     # -- plan / weights ---------------------------------------------------------------------
     def plan(self, mode: int) -> _native.PlanStruct:
@@ -99,18 +107,23 @@ class FusedNet:
         return self._plans[key]
 
     def _param_key(self, device, plan) -> Tuple:
+        """(layout key, parameter versions).  The packed layout is a function of (tile, width, dregs, cregs,
+        n_hidden) -- ff_layout.h make_layout -- and not of the kernel instantiation: the state-only and the
+        divergence-capable kernels of one shape share a buffer."""
         vers = tuple((p.data_ptr(), p._version) for l in self.linears for p in (l.weight, l.bias))
-        return (str(device), plan.width, plan.dregs, plan.cregs, vers)
+        return (str(device), plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden), vers
 
     def wpack(self, device, mode: int) -> torch.Tensor:
         plan = self.plan(mode)
-        key = self._param_key(device, plan)
-        if self._wpack is None or self._wpack[0] != key:
+        layout, vers = self._param_key(device, plan)
+        hit = self._wpack.get(layout)
+        if hit is None or hit[0] != vers:
             packed = _native.pack_weights(
                 plan, [l.weight for l in self.linears], [l.bias for l in self.linears],
                 self.hidden, self.x_col0, self.c_col0)
-            self._wpack = (key, packed.to(device))
-        return self._wpack[1]
+            hit = (vers, packed.to(device))
+            self._wpack[layout] = hit
+        return hit[1]
 
     # -- launch -----------------------------------------------------------------------------
     def integrate(self, x: torch.Tensor, etab: torch.Tensor, mode: int = MODE_STATE,

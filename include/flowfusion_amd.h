@@ -74,6 +74,16 @@ extern "C" {
 #define FF_ACT_GELU_TANH   8    /* nn.GELU(approximate="tanh")                             */
 #define FF_ACT_COUNT       9
 
+/* Arithmetic of the Linear layers (ff_mlp_plan_t.precision).
+ *   FF_PREC_F32     exact fp32 FMA chains on the f32 MFMAs -- what the reference computes; the default.
+ *   FF_PREC_BF16X3  opt-in: every operand is split into three bf16 parts (hi + mid + lo carry 24 mantissa
+ *                   bits) and a product is the sum of the six bf16 MFMAs whose parts' exponents sum to more than
+ *                   2^-24 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32: fp32-class
+ *                   accuracy (error ~1e-7 relative to sum |w||x|, like an fp32 dot product) at the bf16 matrix
+ *                   rate.  State-only and Hutchinson modes, SiLU networks; see DESIGN.md for coverage. */
+#define FF_PREC_F32        0
+#define FF_PREC_BF16X3     1
+
 /* evaluation-row flag bits (word 3 of the row header) */
 #define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */
 #define FF_ROW_NOISE       2u   /* after the step update: y += gn * noise[noise_index]     */
@@ -93,7 +103,7 @@ typedef struct ff_mlp_plan_t {
     int32_t tile;        /* MFMA columns per wavefront: 32 (32x32x2 f32) or 16 (16x16x4)  */
     int32_t activation;  /* FF_ACT_*                                                      */
     float   act_param[2];/* parameters of the activation (see FF_ACT_*), else 0           */
-    int32_t reserved;
+    int32_t precision;   /* FF_PREC_*: arithmetic of the Linear layers (0 = exact fp32, the default)     */
 } ff_mlp_plan_t;
 
 /* Arguments of one fused integration launch. */
@@ -177,7 +187,12 @@ int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, i
 int ff_mlp_plan_act(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
                     int activation, const float* act_param, ff_mlp_plan_t* plan_out);
 
-/* Floats in the packed weight buffer of a plan. */
+/* The same with an explicit arithmetic (FF_PREC_*); FF_ERR_UNSUPPORTED if no instantiation of that family
+ * covers the shape / mode / activation.  ff_mlp_plan_act(...) is ff_mlp_plan_prec(..., FF_PREC_F32, ...). */
+int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
+                     int activation, const float* act_param, int precision, ff_mlp_plan_t* plan_out);
+
+/* Floats (4-byte units) in the packed weight buffer of a plan. */
 size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan);
 
 /*
@@ -212,6 +227,41 @@ int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode);
 
 /* hipError_t of the most recent failing launch on this thread (0 if none). */
 int ff_last_hip_error(void);
+
+/* ---- streaming helpers beside the fused integrator (csrc/ff_aux.hip) --------------------------------- */
+
+/* Noise index reserved for the prior draw of a sample in the counter-based stream (never used by the
+ * Euler-Maruyama rows, which count from rng_noise_base upwards). */
+#define FF_PRIOR_NOISE_INDEX 0xFFFFFFFFu
+
+/*
+ * out[r][d] = scale * z(seed, global row sample_offset + r, noise_index, d)  for r < batch, d < dim, with z the
+ * standard normal of the in-kernel stream defined at ff_ode_args.rng_seed (Philox4x32-10 + Box-Muller).
+ * Replaces the prior draw `self.sde.prior(dims).sample([batch])` of sample_sde (diffusion.py:532-536; the
+ * priors are Normal(0, 1) :1093 and Normal(0, sigma_max) :1003, hence `scale`) when a batch is sharded over
+ * GPUs: each rank fills only its rows and every world size starts from the same points.  `out` is a DEVICE
+ * pointer to [batch, dim] contiguous fp32.  Enqueues on hip_stream.
+ */
+int ff_normal_fill(float* out, int64_t batch, int32_t dim, uint64_t seed, int64_t sample_offset,
+                   uint32_t noise_index, float scale, void* hip_stream);
+
+/*
+ * out = x_coef * x + sum_s coef[s] * k[s]   over n contiguous fp32 elements (DEVICE pointers; x may be NULL,
+ * k[s] is not read when coef[s] == 0; out may alias x or a k[s]).
+ * The stage-input, step-update, dense-output and error-estimate algebra of an explicit Runge-Kutta step for a
+ * right-hand side evaluated OUTSIDE the library -- the reference accepts any `model=` module in ScoreModel
+ * (diffusion.py:201,233-238) and hands the stepping to torchdiffeq (call sites diffusion.py:631-639, 744-752),
+ * which spends one elementwise pass over the state per term; this is one pass per combination.
+ */
+typedef struct ff_combine_args {
+    const float* x;
+    const float* k[FF_MAX_SLOTS];
+    float        coef[FF_MAX_SLOTS];
+    float        x_coef;
+    float*       out;
+    int64_t      n;
+} ff_combine_args;
+int ff_stage_combine(const ff_combine_args* args, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -292,6 +292,38 @@ class ScoreOracle:
         return x_mean
 
 
+class PopulationOracle:
+    """diffusion.py:1466-1640 (PopulationModelDiffusion) and :1643-1848 (...Conditional) restated: affine
+    pre-/post-processing around a ScoreOracle.  ``cshift``/``cscale`` None = the unconditional wrapper."""
+
+    def __init__(self, score: ScoreOracle, shift, scale, cshift=None, cscale=None, method="dopri5", options=None):
+        dt = score.dtype
+        self.score, self.method, self.options = score, method, options
+        self.shift, self.scale = shift.to(dt), scale.to(dt)
+        self.cshift = None if cshift is None else cshift.to(dt)
+        self.cscale = None if cscale is None else cscale.to(dt)
+
+    def _cond(self, conditional):                                     # :1776, :1809, :1839
+        return None if self.cshift is None else (conditional - self.cshift) / self.cscale
+
+    def forward(self, base, conditional=None):
+        """:1575-1585 / :1772-1784: sample_ode_from_base(method=self.method, atol=rtol=1e-5) * scale + shift."""
+        x = self.score.sample_ode_from_base(base, self._cond(conditional), self.method, self.options, 1e-5, 1e-5)
+        return x * self.scale + self.shift
+
+    def sample_sde(self, x_prior, noise, conditional=None):
+        """:1608 / :1805-1814: always 100 steps (the wrapper ignores its `steps`), then * scale + shift."""
+        return self.score.sample_sde(x_prior, noise, self._cond(conditional), steps=100) * self.scale + self.shift
+
+    def log_prob(self, x, conditional=None, atol=1e-5, rtol=1e-5, divergence="exact", e=None):
+        """:1632-1640 / :1837-1848: solve_odes_forward((x - shift)/scale, atol, rtol, options=self.options) --
+        `self.method` is NOT forwarded, so the solver default (dopri5) applies -- plus the prior log-density;
+        no log|scale| term."""
+        xT, lp = self.score.solve_odes_forward((x - self.shift) / self.scale, self._cond(conditional), "dopri5",
+                                               self.options, divergence, e, atol, rtol)
+        return lp + torch.sum(normal_log_prob(xT, self.score.sde.prior_scale()), dim=1, keepdim=True)
+
+
 # =================================================================================================
 # fixed-grid ODE stepping (restatement of torchdiffeq's algorithm -- see the module docstring)
 # =================================================================================================
@@ -585,16 +617,27 @@ class FlowOracle:
         (the reference passes no tolerances here, so torchdiffeq's defaults apply)."""
         times = torch.tensor([1.0, 0.0], dtype=torch.float32).to(self.dtype)
         with torch.no_grad():
-            func = lambda t, y: (self.dynamics(t, y[0], conditional),)
-            (x0,) = odeint(func, (xT,), times, method, options, rtol, atol)
+            if conditional is None:
+                func = lambda t, y: (self.dynamics(t, y[0]),)
+                (x0,) = odeint(func, (xT,), times, method, options, rtol, atol)
+            else:      # the conditional rides in the state with a zero derivative, flow.py:591-596, 792-796
+                func = lambda t, y: (self.dynamics(t, y[0], y[1]), torch.zeros_like(y[1]))
+                x0, _ = odeint(func, (xT, conditional), times, method, options, rtol, atol)
         return x0 * self.p.target_scale + self.p.target_shift
 
     def solve_ode_forward(self, x, conditional=None, method="rk4", options=None, atol=1e-5, rtol=1e-5):
         """flow.py:347-384 / :844-883 -> (xT, log_jacobian[B,1])."""
         logj = torch.zeros(x.shape[0], 1, dtype=x.dtype)
         times = torch.tensor([0.0, 1.0], dtype=torch.float32).to(self.dtype)
-        func = lambda t, y: self.dynamics_with_jacobian(t, y[0], conditional)
-        return odeint(func, (x, logj), times, method, options, rtol, atol)
+        if conditional is None:
+            func = lambda t, y: self.dynamics_with_jacobian(t, y[0])
+            return odeint(func, (x, logj), times, method, options, rtol, atol)
+        # state (x, conditional, logJ) with d(conditional)/dt = 0, flow.py:646-652, 869-881
+        def func(t, y):
+            v, div = self.dynamics_with_jacobian(t, y[0], y[1])
+            return v, torch.zeros_like(y[1]), div
+        xT, _, lj = odeint(func, (x, conditional, logj), times, method, options, rtol, atol)
+        return xT, lj
 
     def log_prob(self, x, conditional=None, method="rk4", options=None, atol=1e-5, rtol=1e-5):
         """flow.py:420-438 / :922-941 -> [B]."""

@@ -685,12 +685,22 @@ def test_sample_sde_philox_public_api_and_sharded_helper():
     assert not torch.equal(c, d)
     with pytest.raises(ValueError):
         sm.sample_sde((8, 16), steps=5, noise="curand")
-    # single process: the sharded helper is the whole batch; its rows do not depend on the partition
+    # single process: the sharded helper is the whole batch; its rows do not depend on the partition.  The prior
+    # comes from the counter-based stream too (reserved noise index), keyed by the global row: a rank fills only
+    # its rows (ff_normal_fill) and gets the numbers the whole-batch fill has there, bit for bit
+    from flowfusion_amd import _native
+    from tests._philox import normals
     full = sample_sde_sharded(sm, (777, 16), steps=20, seed=42)
-    gen = torch.Generator(device=DEV).manual_seed(42)
-    unit = torch.randn((777, 16), generator=gen, device=DEV)
+    prior = _native.normal_fill(777, 16, 42, 0, DEV)
     lo, hi = 300, 500
-    part = sm._sample_sde_from(unit[lo:hi].contiguous(), None, None, 20, rng=(42, lo))
+    assert torch.equal(_native.normal_fill(hi - lo, 16, 42, lo, DEV), prior[lo:hi])
+    ref = torch.from_numpy(normals(42, 0, 777, 16, [_native.PRIOR_NOISE_INDEX]))[0]
+    assert (prior.cpu() - ref).abs().max().item() < 2e-6                      # hardware log / sin / cos vs numpy
+    assert abs(float(prior.mean())) < 0.03 and abs(float(prior.std()) - 1.0) < 0.03
+    odd = _native.normal_fill(33, 7, 9, 12345678901, DEV, noise_index=5, scale=2.5)          # dim % 4 != 0, 64-bit rows
+    ref = torch.from_numpy(normals(9, 12345678901, 33, 7, [5]))[0] * 2.5
+    assert (odd.cpu() - ref).abs().max().item() < 5e-6
+    part = sm._sample_sde_from(prior[lo:hi].contiguous(), None, None, 20, rng=(42, lo))
     assert torch.equal(part, full[lo:hi])
     # same distribution as the torch-noise sampler (two independent draws of 20000 samples: moments agree)
     torch.manual_seed(0)

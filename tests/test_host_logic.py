@@ -467,3 +467,31 @@ def test_population_wrappers_load_reference_state_and_sample(name, built_library
     x, _ = _emulate_score(sm, a["x_prior"], table, MODE_STATE, cn, noise=a["noise"])
     got = x * pm.scale.double() + pm.shift.double()                   # :1606-1609
     assert max_rel(got, a["out"], floor=a["out"].abs().max().item()) < 3e-5
+
+
+def test_replaced_layer_invalidates_the_fused_view(built_library):
+    """A layer swapped after the first solve (layer surgery, re-initialisation) must be repacked: the kernel-side
+    view is rebuilt when ANY Linear module changed identity, not only the first.  Also: the state-only and the
+    divergence kernels of one shape share one packed buffer (the layout does not depend on the instantiation)."""
+    sm = D.ScoreModel(D.MLP(4, 0, 8, [64, 64, 64]), D.VPSDE(), no_sigma=True).eval()
+    net = sm._net()
+    w0 = net.wpack("cpu", MODE_STATE).clone()
+    assert sm._net() is net
+    assert net.wpack("cpu", MODE_HUTCH) is net.wpack("cpu", MODE_STATE)
+    torch.manual_seed(123)
+    sm.model.NN[1] = torch.nn.Linear(64, 64)
+    net2 = sm._net()
+    assert net2 is not net and net2.linears[1] is sm.model.NN[1]
+    w1 = net2.wpack("cpu", MODE_STATE)
+    assert w1.shape == w0.shape and not torch.equal(w0, w1)
+    # in-place updates keep the view and refresh the pack
+    with torch.no_grad():
+        sm.model.NN[2].weight.mul_(2.0)
+    assert sm._net() is net2 and not torch.equal(net2.wpack("cpu", MODE_STATE), w1)
+    # a changed activation rebuilds it as well
+    sm.model.activation = torch.nn.Tanh()
+    assert sm._net() is not net2
+    f = F.ODEFlow(3, [64, 64])
+    nf = f._net()
+    f.layers[2] = torch.nn.Linear(64, 64)
+    assert f._net() is not nf

@@ -13,6 +13,16 @@ import sys
 from pathlib import Path
 
 
+def _head_commit():
+    """Commit the profiled tree was snapshotted from (the summariser runs in the authoring container, where git is)."""
+    import subprocess
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              cwd=Path(__file__).resolve().parents[1]).stdout.strip() or None
+    except OSError:
+        return None
+
+
 def find(root: Path, suffix: str):
     hits = sorted(root.rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -90,7 +100,7 @@ def main(src: Path, dst: Path):
     (dst / "bench_c2_pmc_summary.json").write_text(json.dumps(summary, indent=1))
     (dst.parent / "hbm_traffic.json").write_text(json.dumps(
         {"bytes_per_launch": read_b + write_b, "source": f"{dst}/bench_c2_pmc_summary.json", "kernel": kernel_full,
-         "batch": B}, indent=1))
+         "batch": B, "commit": _head_commit()}, indent=1))
     print(json.dumps({k: summary[k] for k in ("kernel", "bytes_per_launch", "effective_clock_GHz",
                                                 "mfma_pipe_busy_fraction")}, indent=1))
 
