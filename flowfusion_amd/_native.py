@@ -23,6 +23,10 @@ MODE_STATE = 0
 MODE_HUTCH = 1
 MODE_EXACT = 2
 
+# FF_PREC_* of include/flowfusion_amd.h
+PREC_F32, PREC_BF16X3 = 0, 1
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3}
+
 # FF_ACT_* of include/flowfusion_amd.h
 ACT_SILU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SOFTPLUS, ACT_GELU, ACT_GELU_TANH = range(9)
 
@@ -121,6 +125,12 @@ def lib() -> ctypes.CDLL:
     L.ff_mlp_plan_act.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                   ctypes.POINTER(PlanStruct)]
+    L.ff_mlp_plan_prec.restype = ctypes.c_int
+    L.ff_mlp_plan_prec.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                   ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.c_int,
+                                   ctypes.POINTER(PlanStruct)]
+    L.ff_plan_kernel_name.restype = ctypes.c_char_p
+    L.ff_plan_kernel_name.argtypes = [ctypes.POINTER(PlanStruct)]
     L.ff_mlp_wpack_floats.restype = ctypes.c_size_t
     L.ff_mlp_wpack_floats.argtypes = [ctypes.POINTER(PlanStruct)]
     L.ff_mlp_wpack.restype = ctypes.c_int
@@ -148,12 +158,17 @@ def _err(rc: int, what: str) -> RuntimeError:
 
 
 def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
-              act: Tuple[int, float, float] = (ACT_SILU, 0.0, 0.0)) -> PlanStruct:
-    """ff_mlp_plan_act: pick the compiled kernel for this network shape (raises if none fits)."""
+              act: Tuple[int, float, float] = (ACT_SILU, 0.0, 0.0), precision: int = PREC_F32) -> PlanStruct:
+    """ff_mlp_plan_prec: pick the compiled kernel for this network shape (raises if none fits)."""
     p = PlanStruct()
     arr = (ctypes.c_int * len(hidden))(*hidden)
     prm = (ctypes.c_float * 2)(float(act[1]), float(act[2]))
-    rc = lib().ff_mlp_plan_act(dim, cond_dim, len(hidden), arr, mode, int(act[0]), prm, ctypes.byref(p))
+    rc = lib().ff_mlp_plan_prec(dim, cond_dim, len(hidden), arr, mode, int(act[0]), prm, int(precision), ctypes.byref(p))
+    if rc == FF_ERR_UNSUPPORTED and precision == PREC_BF16X3:
+        raise NotImplementedError(
+            f"precision='bf16x3' has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
+            f"activation={act[0]}: the split-precision family covers SiLU networks of 1-6 hidden layers up to 256 wide, "
+            "dim <= 16, cond_dim <= 16, state-only and Hutchinson solves on a fixed grid; use precision='f32'")
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
@@ -179,6 +194,12 @@ def pack_weights(plan: PlanStruct, weights: List[torch.Tensor], biases: List[Opt
     if rc != FF_OK:
         raise _err(rc, "ff_mlp_wpack")
     return out
+
+
+def kernel_name(plan: PlanStruct) -> str:
+    """ff_plan_kernel_name: the instantiation a plan selects."""
+    n = lib().ff_plan_kernel_name(ctypes.byref(plan))
+    return n.decode() if n else "?"
 
 
 def samples_per_workgroup(plan: PlanStruct, mode: int) -> int:

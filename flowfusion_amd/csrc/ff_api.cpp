@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include "flowfusion_amd.h"
 #include "ff_layout.h"
+#include "ff_split_layout.h"
 #include "ff_registry.h"
 
 static_assert(FF_MAX_SLOTS == ff::kSlots, "slot count mismatch between header and kernel");
@@ -13,14 +14,15 @@ static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
 
 static thread_local int t_last_hip_error = 0;
 
-extern "C" const char* ff_version(void) { return "flowfusion_amd 0.1 gfx950 (f32 MFMA 16x16x4 / 32x32x2, in-register layer chaining)"; }
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.2 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 split on 32x32x16 bf16; in-register layer chaining)"; }
 
-extern "C" int ff_kernel_count(void) { return ff::g_n_kernels; }
+extern "C" int ff_kernel_count(void) { return ff::g_n_kernels + ff::g_n_split_kernels; }
 
+// ids [0, n) are the fp32 instantiations (plan.kernel_id of an FF_PREC_F32 plan), [n, n + m) the split-precision ones
 extern "C" const char* ff_kernel_name(int id)
 {
-    if (id < 0 || id >= ff::g_n_kernels) return NULL;
-    return ff::g_kernels[id].name;
+    if (id < 0 || id >= ff::g_n_kernels + ff::g_n_split_kernels) return NULL;
+    return id < ff::g_n_kernels ? ff::g_kernels[id].name : ff::g_split_kernels[id - ff::g_n_kernels].name;
 }
 
 extern "C" int ff_last_hip_error(void) { return t_last_hip_error; }
@@ -34,6 +36,42 @@ static int tangents_of_mode(int mode, int dim, int tile, int* n_tangent, int* un
     case FF_MODE_EXACT: *n_tangent = dim < tile - 1 ? dim : tile - 1; *unit = 1; return 0;
     default: return FF_ERR_BADARG;
     }
+}
+
+// FF_PREC_BF16X3: the split-precision family (ff_mlp_ode_split.hpp) -- SiLU, width <= 32 nt, dim <= 16,
+// cond_dim <= 16, state-only or Hutchinson, the number of hidden layers compiled in
+static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode, int activation,
+                      ff_mlp_plan_t* plan)
+{
+    if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
+    if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
+    if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
+    if (activation != FF_ACT_SILU || mode == FF_MODE_EXACT || dim > 16 || cond_dim > 16) return FF_ERR_UNSUPPORTED;
+    int wmax = 0;
+    for (int i = 0; i < n_hidden; ++i) {
+        if (hidden_widths[i] < 1) return FF_ERR_BADARG;
+        if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
+    }
+    const int need_t = mode != FF_MODE_STATE, need_k = cond_dim > 0 ? 2 : 1;
+    int best = -1;
+    for (int i = 0; i < ff::g_n_split_kernels; ++i) {
+        const ff::SplitKernelEntry& k = ff::g_split_kernels[i];
+        if (32 * k.nt < wmax || k.k1s != need_k || k.n_hidden != n_hidden || k.tangents != need_t) continue;
+        if (best < 0 || k.nt < ff::g_split_kernels[best].nt) best = i;
+    }
+    if (best < 0) return FF_ERR_UNSUPPORTED;
+    memset(plan, 0, sizeof(*plan));
+    plan->dim = dim;
+    plan->cond_dim = cond_dim;
+    plan->n_hidden = n_hidden;
+    plan->width = 32 * ff::g_split_kernels[best].nt;
+    plan->dregs = 8;                                   // 16 dimensions over the two lane halves
+    plan->cregs = cond_dim > 0 ? 8 : 0;
+    plan->kernel_id = best;
+    plan->tile = 32;
+    plan->activation = FF_ACT_SILU;
+    plan->precision = FF_PREC_BF16X3;
+    return FF_OK;
 }
 
 extern "C" int ff_mlp_plan(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
@@ -52,7 +90,7 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
                                 int activation, const float* act_param, int precision, ff_mlp_plan_t* plan)
 {
     if (precision != FF_PREC_F32 && precision != FF_PREC_BF16X3) return FF_ERR_BADARG;
-    if (precision == FF_PREC_BF16X3) return FF_ERR_UNSUPPORTED;
+    if (precision == FF_PREC_BF16X3) return plan_split(dim, cond_dim, n_hidden, hidden_widths, mode, activation, plan);
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
     // FF_ANY_ACT=1 sends SiLU networks to the run-time-activation kernels as well (A/B tests)
@@ -98,13 +136,22 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
     return FF_OK;
 }
 
+static bool plan_ok_split(const ff_mlp_plan_t* p)
+{
+    if (!p || p->precision != FF_PREC_BF16X3 || p->kernel_id < 0 || p->kernel_id >= ff::g_n_split_kernels) return false;
+    const ff::SplitKernelEntry& k = ff::g_split_kernels[p->kernel_id];
+    return p->width == 32 * k.nt && p->tile == 32 && p->dregs == 8 && p->cregs == (k.k1s > 1 ? 8 : 0) &&
+           p->n_hidden == k.n_hidden && p->activation == FF_ACT_SILU && p->dim >= 1 && p->dim <= 16 &&
+           p->cond_dim >= 0 && p->cond_dim <= 16 && (p->cond_dim > 0) == (k.k1s > 1);
+}
+
 static bool plan_ok(const ff_mlp_plan_t* p)
 {
-    if (!p || p->kernel_id < 0 || p->kernel_id >= ff::g_n_kernels) return false;
+    if (!p || p->precision != FF_PREC_F32) return false;
+    if (p->kernel_id < 0 || p->kernel_id >= ff::g_n_kernels) return false;
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
     const int per_reg = 64 / k.tile;
     return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
-           p->precision == FF_PREC_F32 &&
            p->activation >= 0 && p->activation < FF_ACT_COUNT && (p->activation == FF_ACT_SILU || k.any_act) &&
            p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
 }
@@ -114,15 +161,111 @@ static ff::Layout plan_layout(const ff_mlp_plan_t* p)
     return ff::make_layout(p->tile, p->width, p->dregs, p->cregs, p->n_hidden);
 }
 
+extern "C" const char* ff_plan_kernel_name(const ff_mlp_plan_t* plan)
+{
+    if (plan_ok_split(plan)) return ff::g_split_kernels[plan->kernel_id].name;
+    if (plan_ok(plan)) return ff::g_kernels[plan->kernel_id].name;
+    return NULL;
+}
+
 extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
 {
+    if (plan_ok_split(plan)) {
+        const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
+        return ff::split::total_words(k.nt, k.k1s, k.n_hidden);
+    }
     if (!plan_ok(plan)) return 0;
     return plan_layout(plan).total_floats;
+}
+
+// three-way bf16 split by truncation: v = hi + mid + lo exactly (8 + 8 + 8 significand bits)
+static inline uint16_t bf16_top(float v, float* rest)
+{
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const uint32_t t = u & 0xFFFF0000u;
+    float tf;
+    memcpy(&tf, &t, 4);
+    *rest = v - tf;
+    return (uint16_t)(t >> 16);
+}
+
+// FF_PREC_BF16X3 packing: the fragment stream of ff_split_layout.h followed by the fp32 biases
+static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
+                       const int* hidden_widths, int in_features0, int x_col0, int c_col0, float* out)
+{
+    namespace sp = ff::split;
+    const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
+    const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden, NT = k.nt;
+    uint32_t* words = (uint32_t*)out;
+    memset(out, 0, sp::total_words(NT, k.k1s, NH) * 4);
+    size_t group = 0;                                  // running group index in the stream
+    // one group: fragments [hi, mid, lo] of row tile t; element (lane half h, j) multiplies input column col(h, j)
+    auto put_group = [&](const float* Wl, int rows, int ld, int t, auto col) {
+        uint32_t* g = words + group * (sp::kGroupFrags * sp::kFragBytes / 4);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int row = 32 * t + (lane & 31), c = col(lane >> 5, j);
+                const float v = (row < rows && c >= 0) ? Wl[(size_t)row * ld + c] : 0.f;
+                float r1, r2, r3;
+                const uint16_t part[3] = {bf16_top(v, &r1), bf16_top(r1, &r2), bf16_top(r2, &r3)};
+                for (int p = 0; p < 3; ++p) {
+                    uint32_t& w = g[p * 256 + lane * 4 + (j >> 1)];
+                    w = (j & 1) ? ((w & 0x0000FFFFu) | ((uint32_t)part[p] << 16)) : ((w & 0xFFFF0000u) | part[p]);
+                }
+            }
+        ++group;
+    };
+    // layer 1: k-step 0 = state dimensions, k-step 1 = conditional inputs
+    for (int s = 0; s < k.k1s; ++s)
+        for (int t = 0; t < NT; ++t)
+            put_group(W[0], hidden_widths[0], in_features0, t, [&](int h, int j) {
+                const int d = sp::kidx(0, h, j);
+                return s == 0 ? (d < D ? x_col0 + d : -1) : (d < C ? c_col0 + d : -1);
+            });
+    group = sp::groups_l1(NT, k.k1s);
+    // hidden -> hidden, k-major: pair p, tile t, k-steps 2p and 2p+1
+    for (int l = 1; l < NH; ++l) {
+        const int win = hidden_widths[l - 1], wout = hidden_widths[l];
+        for (int p = 0; p < NT; ++p)
+            for (int t = 0; t < NT; ++t)
+                for (int u = 0; u < 2; ++u)
+                    put_group(W[l], wout, win, t, [&](int h, int j) {
+                        const int kk = sp::kidx(2 * p + u, h, j);
+                        return kk < win ? kk : -1;
+                    });
+        group = sp::groups_l1(NT, k.k1s) + (size_t)l * sp::groups_hid(NT);
+        float* bo = out + sp::stream_words(NT, k.k1s, NH) + (size_t)(l - 1) * H;
+        for (int row = 0; row < wout; ++row) bo[row] = b[l][row];
+    }
+    // output layer: one row tile, all k-steps
+    {
+        const int win = hidden_widths[NH - 1];
+        for (int s = 0; s < 2 * NT; ++s)
+            put_group(W[NH], D, win, 0, [&](int h, int j) {
+                const int kk = sp::kidx(s, h, j);
+                return kk < win ? kk : -1;
+            });
+        float* bo = out + sp::stream_words(NT, k.k1s, NH) + (size_t)(NH - 1) * H;
+        for (int row = 0; row < D; ++row) bo[row] = b[NH][row];
+    }
+    return FF_OK;
 }
 
 extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
                             const int* hidden_widths, int in_features0, int x_col0, int c_col0, float* out)
 {
+    if (plan_ok_split(plan)) {
+        if (!W || !b || !hidden_widths || !out) return FF_ERR_BADARG;
+        const int D = plan->dim, C = plan->cond_dim, NH = plan->n_hidden;
+        if (x_col0 < 0 || x_col0 + D > in_features0) return FF_ERR_BADARG;
+        if (C > 0 && (c_col0 < 0 || c_col0 + C > in_features0)) return FF_ERR_BADARG;
+        for (int i = 0; i < NH; ++i)
+            if (hidden_widths[i] < 1 || hidden_widths[i] > plan->width) return FF_ERR_BADARG;
+        for (int i = 0; i <= NH; ++i)
+            if (!W[i] || (i > 0 && !b[i])) return FF_ERR_BADARG;
+        return wpack_split(plan, W, b, hidden_widths, in_features0, x_col0, c_col0, out);
+    }
     if (!plan_ok(plan) || !W || !b || !hidden_widths || !out) return FF_ERR_BADARG;
     const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden;
     if (x_col0 < 0 || x_col0 + D > in_features0) return FF_ERR_BADARG;
@@ -184,6 +327,10 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
 
 extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
 {
+    if (plan_ok_split(plan)) {
+        if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH) return FF_ERR_BADARG;
+        return mode == FF_MODE_STATE ? 128 : 64;
+    }
     if (!plan_ok(plan)) return FF_ERR_BADARG;
     int nt, unit;
     int rc = tangents_of_mode(mode, plan->dim, plan->tile, &nt, &unit);
@@ -191,8 +338,41 @@ extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
     return 4 * (plan->tile / (1 + nt));
 }
 
+// FF_PREC_BF16X3 launch: state-only / Hutchinson integration of a table without noise rows
+static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
+{
+    if (!a->x_in || !a->x_out || !a->wpack || !a->etab || a->batch < 0 || a->n_evals < 0) return FF_ERR_BADARG;
+    if (plan->cond_dim > 0 && !a->cond) return FF_ERR_BADARG;
+    const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
+    if (a->mode != FF_MODE_STATE && a->mode != FF_MODE_HUTCH) return a->mode == FF_MODE_EXACT ? FF_ERR_UNSUPPORTED : FF_ERR_BADARG;
+    if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
+    if (a->mode == FF_MODE_HUTCH && (!a->probe || !a->dlogp_out)) return FF_ERR_BADARG;
+    // what this family does not carry: noise rows, adaptive-step inputs / outputs, the Jacobian output
+    if (a->noise || a->k1_in || a->kl1_in || a->n_aux != 0 || a->jac_out) return FF_ERR_UNSUPPORTED;
+    if (a->batch == 0) return FF_OK;
+    ff::KernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.x_in = a->x_in; ka.x_out = a->x_out; ka.cond = a->cond; ka.probe = a->probe;
+    ka.dlogp_out = a->dlogp_out; ka.wpack = a->wpack; ka.etab = a->etab;
+    ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
+    ka.status = a->status; ka.batch = a->batch; ka.dlogp_in = a->dlogp_in;
+    ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
+    ka.n_tangent = k.tangents ? 1 : 0;
+    ka.etab_stride = FF_ROW_HDR + plan->width;
+    if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
+    ka.wpack_floats = (int)ff::split::total_words(k.nt, k.k1s, k.n_hidden);
+    const long long spw = k.tangents ? 64 : 128;
+    const long long grid = (a->batch + spw - 1) / spw;
+    if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
+    const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden).total;
+    const int herr = k.launch(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
+    if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
+    return FF_OK;
+}
+
 extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
 {
+    if (a && plan_ok_split(plan)) return launch_split(plan, a, hip_stream);
     if (!plan_ok(plan) || !a) return FF_ERR_BADARG;
     if (!a->x_in || !a->x_out || !a->wpack || !a->etab || a->batch < 0 || a->n_evals < 0) return FF_ERR_BADARG;
     if (plan->cond_dim > 0 && !a->cond) return FF_ERR_BADARG;

@@ -49,11 +49,12 @@ class _FlowBase(nn.Module):
         act = next(iter(specs))
         lin = self._linears()
         cached = getattr(self, "_fused", None)
-        if cached is None or not cached.serves(lin, act):
+        prec = getattr(self, "precision", "f32")       # extension: "bf16x3" = split-precision kernels (see ScoreModel)
+        if cached is None or not cached.serves(lin, act, prec):
             D = self.target_dimension
             C = getattr(self, "conditional_dimension", 0)
             # first-layer columns: [x (D) | t (1) | cond (C)]
-            object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1, act=act))
+            object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1, act=act, precision=prec))
         return self._fused
 
     def _schedule(self, t, first=None):

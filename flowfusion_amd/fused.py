@@ -72,9 +72,12 @@ class FusedNet:
     ``[ time part | x | cond ]`` in any column order."""
 
     def __init__(self, linears: Sequence[nn.Linear], dim: int, cond_dim: int, x_col0: int, c_col0: int,
-                 act: Tuple[int, float, float] = (_native.ACT_SILU, 0.0, 0.0)):
+                 act: Tuple[int, float, float] = (_native.ACT_SILU, 0.0, 0.0), precision: str = "f32"):
         self.linears = list(linears)
         self.act = (int(act[0]), float(act[1]), float(act[2]))
+        if precision not in _native.PRECISIONS:
+            raise ValueError(f"precision={precision!r}: expected one of {sorted(_native.PRECISIONS)}")
+        self.precision = precision
         if len(self.linears) < 2:
             raise NotImplementedError("the fused path needs at least one hidden layer")
         self.dim = int(dim)
@@ -91,19 +94,20 @@ class FusedNet:
         self._wpack = {}            # layout key -> (parameter versions, packed device tensor)
         self._tables = {}           # small cache of evaluation tables already on the device
 
-    def serves(self, linears, act) -> bool:
+    def serves(self, linears, act, precision: str = "f32") -> bool:
         """True if this view was built from exactly these Linear modules (identity, in order) and this
         activation.  The front ends rebuild the view otherwise: a layer replaced after the first solve
         (``model.NN[2] = nn.Linear(..)``) must not keep integrating with the old weights."""
         act = (int(act[0]), float(act[1]), float(act[2]))
-        return (self.act == act and len(linears) == len(self.linears)
+        return (self.act == act and self.precision == precision and len(linears) == len(self.linears)
                 and all(a is b for a, b in zip(linears, self.linears)))
 
     # -- plan / weights ---------------------------------------------------------------------
     def plan(self, mode: int) -> _native.PlanStruct:
         key = 0 if mode == MODE_STATE else (1 if mode == MODE_HUTCH else 2)
         if key not in self._plans:
-            self._plans[key] = _native.make_plan(self.dim, self.cond_dim, self.hidden, mode, self.act)
+            self._plans[key] = _native.make_plan(self.dim, self.cond_dim, self.hidden, mode, self.act,
+                                                 _native.PRECISIONS[self.precision])
         return self._plans[key]
 
     def _param_key(self, device, plan) -> Tuple:
@@ -111,7 +115,7 @@ class FusedNet:
         n_hidden) -- ff_layout.h make_layout -- and not of the kernel instantiation: the state-only and the
         divergence-capable kernels of one shape share a buffer."""
         vers = tuple((p.data_ptr(), p._version) for l in self.linears for p in (l.weight, l.bias))
-        return (str(device), plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden), vers
+        return (str(device), plan.precision, plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden), vers
 
     def wpack(self, device, mode: int) -> torch.Tensor:
         plan = self.plan(mode)
@@ -141,6 +145,8 @@ class FusedNet:
         if x.dim() != 2 or x.shape[1] != self.dim:
             raise ValueError(f"expected a [batch, {self.dim}] state, got {tuple(x.shape)}")
         dev = x.device
+        if self.precision != "f32" and (noise is not None or rng is not None or bool((etab[:, 3].view(torch.int32) & 2).any())):
+            raise NotImplementedError(f"precision={self.precision!r} integrates ODEs only (no Euler-Maruyama noise rows)")
         plan = self.plan(mode)
         f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
         if self.cond_dim > 0:
@@ -187,6 +193,10 @@ class FusedNet:
         the time-dependent scalars and first-layer bias; ``sign`` = -1 for a decreasing span (solved
         in reversed time with the right-hand side negated).  ``launcher`` replaces the GPU launch in
         the CPU tests (kernel-semantics emulator)."""
+        if self.precision != "f32":
+            raise NotImplementedError(
+                f"precision={self.precision!r} integrates on fixed grids only; the adaptive dopri5 path (one launch per "
+                "attempted step) runs on the f32 kernels: pass method='rk4' / 'euler' / ... with options={'step_size': h}")
         plan = self.plan(mode)
         width = plan.width
         words = _native.plan_words(plan)

@@ -170,9 +170,12 @@ typedef struct ff_ode_args {
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */
 const char* ff_version(void);
 
-/* Number of compiled kernel instantiations, and a printable description of each. */
+/* Number of compiled kernel instantiations, and a printable description of each (ids [0, n_f32) are the fp32
+ * family in ff_mlp_plan_t.kernel_id order, the split-precision family follows). */
 int ff_kernel_count(void);
 const char* ff_kernel_name(int kernel_id);
+/* Name of the instantiation a plan selects (either family), NULL for an invalid plan. */
+const char* ff_plan_kernel_name(const struct ff_mlp_plan_t* plan);
 
 /*
  * Choose the kernel instantiation for a network: `hidden_widths[n_hidden]` are the

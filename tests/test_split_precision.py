@@ -1,0 +1,289 @@
+"""precision="bf16x3": the opt-in split-precision kernels (csrc/ff_mlp_ode_split.hpp, FF_PREC_BF16X3).
+
+CPU tier: plan selection, the host packer (the fragment stream decodes back to the fp32 weights bit for bit:
+hi + mid + lo is an exact three-way split), error behaviour.
+GPU tier: the same parity battery the f32 path passes -- golden hybrids, oracle fp32 / fp64 on seeded inputs
+(BASELINE configs 2 and 3 included), ragged batches, Hutchinson tangents, conditional inputs, flows -- at the SAME
+tolerances (2e-5; north_star's bar for log_prob is 1e-4): six bf16 products per term carry ~24 significand bits, so
+the split path sits at fp32 rounding level, not at bf16 level (a single-product bf16 path would miss by 1e-2).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from flowfusion_amd import _native
+from flowfusion_amd import diffusion as D
+from flowfusion_amd import flow as F
+from flowfusion_amd.fused import MODE_EXACT, MODE_HUTCH, MODE_STATE
+from tests._util import flow_model, flow_oracle, golden_names, load_golden, max_rel, score_model, score_oracle
+
+DEV = "cuda"
+STATE_TOL = 2e-5
+LOGP_TOL = 2e-5
+
+
+def _kidx(s, h, j):
+    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def _decode_group(words, g):
+    """[32 rows, 16 k-elements as (h, j)] fp32 of group g of the stream: hi + mid + lo."""
+    frag = words[g * 768:(g + 1) * 768].reshape(3, 64, 4)                       # part, lane, word
+    halves = np.stack([frag & 0xFFFF, frag >> 16], axis=-1).reshape(3, 64, 8)   # element j = 2 word + half
+    vals = (halves.astype(np.uint32) << 16).view(np.float32)
+    tot = vals[0].astype(np.float64) + vals[1].astype(np.float64) + vals[2].astype(np.float64)
+    return tot.astype(np.float32)                                               # [lane, j]
+
+
+def test_plan_and_packer_roundtrip(built_library):
+    torch.manual_seed(3)
+    sm = D.ScoreModel(D.MLP(11, 5, 8, [200, 256, 77]), D.VPSDE(), no_sigma=True, precision="bf16x3").eval()
+    net = sm._net()
+    plan = net.plan(MODE_STATE)
+    assert (plan.precision, plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden) == (1, 32, 256, 8, 8, 3)
+    assert _native.kernel_name(plan) == "mlp_ode_split_h256_k2_n3_t0"
+    assert _native.kernel_name(net.plan(MODE_HUTCH)) == "mlp_ode_split_h256_k2_n3_t1"
+    assert _native.samples_per_workgroup(plan, MODE_STATE) == 128
+    assert _native.samples_per_workgroup(net.plan(MODE_HUTCH), MODE_HUTCH) == 64
+    pack = net.wpack("cpu", MODE_STATE)
+    assert net.wpack("cpu", MODE_HUTCH) is pack                      # one layout for both instantiations
+    words = pack.numpy().view(np.uint32)
+    NT, K1S, NH, H = 8, 2, 3, 256
+    n_gran = (8 * K1S + (NH - 1) * 128 + 16) // 8
+    assert words.size == n_gran * 6144 + (NH - 1) * H + 32
+    Ws = [l.weight.detach().numpy() for l in sm.model.NN]
+    bs = [l.bias.detach().numpy() for l in sm.model.NN]
+    E = 8                                                            # time-embedding columns of the first layer (sin, cos of 4 frequencies)
+    g = 0
+    # layer 1: k-step 0 = state columns, k-step 1 = conditional columns
+    for s in range(K1S):
+        for t in range(NT):
+            got = _decode_group(words, g)
+            g += 1
+            for lane in (0, 17, 31, 32, 63):
+                row, h = 32 * t + (lane & 31), lane >> 5
+                for j in range(8):
+                    d = _kidx(0, h, j)
+                    col = (E + d if d < 11 else None) if s == 0 else (E + 11 + d if d < 5 else None)
+                    exp = Ws[0][row, col] if (row < 200 and col is not None) else 0.0
+                    assert got[lane, j] == np.float32(exp)
+    # hidden -> hidden layers, k-major: exact reconstruction of the whole (zero-padded) matrix
+    widths = [200, 256, 77]
+    for l in range(1, NH):
+        rec = np.zeros((H, H), np.float32)
+        for p in range(NT):
+            for t in range(NT):
+                for u in range(2):
+                    got = _decode_group(words, g)
+                    g += 1
+                    for lane in range(64):
+                        for j in range(8):
+                            rec[32 * t + (lane & 31), _kidx(2 * p + u, lane >> 5, j)] = got[lane, j]
+        exp = np.zeros((H, H), np.float32)
+        exp[:widths[l], :widths[l - 1]] = Ws[l]
+        assert np.array_equal(rec, exp)                              # hi + mid + lo == the fp32 weight, bit for bit
+    rec = np.zeros((32, H), np.float32)
+    for s in range(2 * NT):
+        got = _decode_group(words, g)
+        g += 1
+        for lane in range(64):
+            for j in range(8):
+                rec[lane & 31, _kidx(s, lane >> 5, j)] = got[lane, j]
+    exp = np.zeros((32, H), np.float32)
+    exp[:11, :77] = Ws[NH]
+    assert np.array_equal(rec, exp) and g == n_gran * 8
+    tail = pack.numpy()[n_gran * 6144:]
+    assert np.array_equal(tail[:256], bs[1]) and np.array_equal(tail[256:256 + 77], bs[2][:77]) and not tail[256 + 77:512].any()
+    assert np.array_equal(tail[512:512 + 11], bs[3]) and not tail[512 + 11:].any()
+
+
+def test_split_precision_scope_and_errors(built_library):
+    mk = lambda **kw: _native.make_plan(kw.get("dim", 16), kw.get("cond", 0), kw.get("hidden", [256] * 4), kw.get("mode", MODE_STATE),
+                                        kw.get("act", (_native.ACT_SILU, 0.0, 0.0)), _native.PREC_BF16X3)
+    assert mk().precision == 1
+    for bad in (dict(dim=17), dict(cond=17), dict(hidden=[300, 300]), dict(hidden=[64] * 7), dict(mode=MODE_EXACT),
+                dict(act=(_native.ACT_TANH, 0.0, 0.0))):
+        with pytest.raises(NotImplementedError, match="bf16x3"):
+            mk(**bad)
+    with pytest.raises(ValueError, match="precision"):
+        D.ScoreModel(D.MLP(4, 0, 8, [64]), D.VPSDE(), precision="fp8")._net()
+    # a bf16x3 plan is refused by entry points it does not serve, before any HIP call
+    p = mk()
+    a = _native.OdeArgs()
+    assert built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(a), None) == _native.FF_ERR_BADARG
+    # precision is part of the cache key: flipping the attribute rebuilds the kernel-side view
+    sm = D.ScoreModel(D.MLP(4, 0, 8, [64, 64]), D.VPSDE(), no_sigma=True).eval()
+    n32 = sm._net()
+    sm.precision = "bf16x3"
+    n16 = sm._net()
+    assert n16 is not n32 and n16.plan(MODE_STATE).precision == 1 and n32.plan(MODE_STATE).precision == 0
+    with pytest.raises(NotImplementedError, match="fixed grids"):
+        n16.make_step(None, 1.0, MODE_STATE, "cpu")
+
+
+# ---- GPU tier ------------------------------------------------------------------------------------------------------
+def _state_err(got, exp):
+    return max_rel(got.cpu(), exp, floor=exp.abs().max().item())
+
+
+def _logp_err(got, exp):
+    return max_rel(got.cpu(), exp, floor=1.0)
+
+
+def _seeded(Dm, C, units, sde_name, no_sigma, seed):
+    torch.manual_seed(seed)
+    m = D.MLP(n_dimensions=Dm, n_conditionals=C, embedding_dimensions=8, units=units)
+    sm = D.ScoreModel(m, getattr(D, sde_name)(), no_sigma=no_sigma, precision="bf16x3").eval()
+    meta = dict(D=Dm, C=C, E=8, units=units, sde=sde_name, sde_kw={}, no_sigma=no_sigma)
+    arrays = {k: v.detach().clone() for k, v in sm.state_dict().items()}
+    return sm.to(DEV), score_oracle(meta, arrays), score_oracle(meta, arrays, torch.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in golden_names("hybrid_score_") if "cond32" not in n])
+def test_split_against_golden_hybrids(name, built_library):
+    meta, a = load_golden(name)
+    if meta["D"] > 16 or meta["C"] > 16:
+        pytest.skip("outside the split family's shape envelope")
+    sm = score_model(meta, a, DEV)
+    sm.precision = "bf16x3"
+    cond = a.get("cond")
+    cond_d = None if cond is None else cond.to(DEV)
+    for run in meta["runs"]:
+        m, opts = run["method"], {"step_size": run["step_size"]}
+        x0, _ = sm.sample_ode_from_base(a["base"].to(DEV), conditional=cond_d, method=m, options=opts)
+        assert _state_err(x0, a[f"sample_{m}"]) < STATE_TOL, (name, m)
+        sm.hutch = True
+        xd = a[f"x_data_{m}"].to(DEV)
+        tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), m, opts, 1)
+        xT, dlp, _ = sm._net().integrate(xd, tab, 1, cond=cond_d, probe=a[f"e_{m}"].to(DEV))
+        lp = dlp.view(-1, 1) + sm.sde.prior(xT.shape).log_prob(xT).sum(1, keepdim=True)
+        assert _logp_err(lp, a[f"lp_hutch_{m}"]) < LOGP_TOL, (name, m)
+        assert _state_err(xT, a[f"xT_{m}"]) < STATE_TOL
+        sm.hutch = False
+    assert _native.kernel_name(sm._net().plan(0)).startswith("mlp_ode_split")
+
+
+CONFIGS = {
+    "c2_16d_vp_4x256_rk4_100": (16, 0, [256] * 4, "VPSDE", True, "rk4", 100, 777),
+    "c1_2d_ve_3x128_euler50": (2, 0, [128] * 3, "VESDE", False, "euler", 50, 1000),
+    "cond_5d_c3_ragged_subvp": (5, 3, [64, 100], "SUBVPSDE", False, "midpoint", 30, 129),
+    "cond_16d_c16_dopri5_fixed": (16, 16, [256, 256], "VPSDE", True, "dopri5_fixed", 20, 200),
+    "one_hidden_layer": (8, 0, [200], "VESDE", False, "heun3", 25, 333),
+    "six_hidden_layers": (12, 2, [96] * 6, "VPSDE", False, "rk4_classic", 20, 150),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_split_sampling_and_log_prob_against_oracle(name, built_library):
+    Dm, C, units, sde_name, no_sigma, method, nsteps, B = CONFIGS[name]
+    sm, so32, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 11)
+    torch.manual_seed(1234)
+    base = torch.randn(B, Dm)
+    cond = torch.randn(B, C) if C else None
+    cd = None if cond is None else cond.to(DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+    got, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cd, method=method, options=opts)
+    ref64 = so64.sample_ode_from_base(base.double(), None if cond is None else cond.double(), method, opts).float()
+    e_gpu, e_cpu = _state_err(got, ref64), _state_err(so32.sample_ode_from_base(base, cond, method, opts), ref64)
+    assert e_gpu < STATE_TOL, (name, e_gpu, e_cpu)
+    # Hutchinson log-density (value / tangent column pairs): the reference's CPU-drawn probe
+    sm.hutch = True
+    Bl = min(B, 256)
+    x0 = torch.randn(Bl, Dm) * 0.8 + 0.3
+    torch.manual_seed(99)
+    lp = sm.log_prob(x0.to(DEV), conditional=None if cd is None else cd[:Bl], method=method, options=opts)
+    e = sm.e.cpu()
+    ref64 = so64.log_prob(x0.double(), None if cond is None else cond[:Bl].double(), method, opts, "hutch", e.double()).float()
+    assert lp.shape == (Bl, 1)
+    assert _logp_err(lp, ref64) < LOGP_TOL, name
+    # and against the f32 kernels on the same inputs: two fp32-class evaluations of the same thing
+    sm.precision = "f32"
+    torch.manual_seed(99)
+    lp32 = sm.log_prob(x0.to(DEV), conditional=None if cd is None else cd[:Bl], method=method, options=opts)
+    assert _logp_err(lp, lp32.cpu()) < LOGP_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 127, 128, 129, 1000])
+def test_split_ragged_batches(B, built_library):
+    sm, so32, _ = _seeded(16, 0, [64, 64], "VPSDE", True, 15)
+    torch.manual_seed(B)
+    base = torch.randn(B, 16)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 8}
+    got, _ = sm.sample_ode_from_base(base.to(DEV), method="rk4", options=opts)
+    assert _state_err(got, so32.sample_ode_from_base(base, None, "rk4", opts)) < STATE_TOL
+    sm.hutch = True
+    lp = sm.log_prob(base.to(DEV), method="euler", options=opts)
+    assert _logp_err(lp, so32.log_prob(base, None, "euler", opts, "hutch", sm.e.cpu())) < LOGP_TOL
+
+
+@pytest.mark.gpu
+def test_split_flows_and_wrappers(built_library):
+    torch.manual_seed(21)
+    f = F.ConditionalODEFlow(target_dimension=16, conditional_dimension=6, hidden_units=[256, 256, 256],
+                             target_shift=torch.randn(16), target_scale=torch.rand(16) + 0.5,
+                             conditional_shift=torch.randn(6), conditional_scale=torch.rand(6) + 0.5).eval()
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    fo64 = flow_oracle(sd, torch.float64)
+    f = f.to(DEV)
+    f.precision = "bf16x3"
+    xT, cond = torch.randn(200, 16), torch.randn(200, 6) * 2
+    opts = {"step_size": 1.0 / 40}
+    got = f.sample(xT.to(DEV), cond.to(DEV), method="rk4", options=opts)               # output affine in the epilogue
+    assert _state_err(got, fo64.sample(xT.double(), cond.double(), "rk4", opts).float()) < STATE_TOL
+    x = xT[:48] * f.target_scale.cpu() + f.target_shift.cpu()
+    torch.manual_seed(3)
+    lp = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts, hutchinson=True)
+    f.precision = "f32"
+    torch.manual_seed(3)
+    lp32 = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts, hutchinson=True)
+    assert _logp_err(lp, lp32.cpu()) < LOGP_TOL
+    # what the family does not do raises instead of switching arithmetic silently
+    f.precision = "bf16x3"
+    with pytest.raises(NotImplementedError, match="bf16x3"):
+        f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)           # exact trace
+    with pytest.raises(NotImplementedError, match="fixed grids"):
+        f.sample(xT.to(DEV), cond.to(DEV))                                              # adaptive dopri5
+    sm, _, _ = _seeded(4, 0, [64, 64], "VPSDE", True, 5)
+    with pytest.raises(NotImplementedError, match="noise"):
+        sm.sample_sde((16, 4), steps=5)
+
+
+@pytest.mark.gpu
+def test_split_full_size_properties_and_speed(built_library):
+    """BASELINE config 2 at 2^20: determinism, batch-shape invariance (bitwise), oracle on a subsample, agreement
+    with the f32 kernels -- and the reason the family exists: it must be clearly faster."""
+    import time
+    sm, so32, so64 = _seeded(16, 0, [256] * 4, "VPSDE", True, 17)
+    B = 1 << 20
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 100}
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    z = torch.randn(B, 16, device=DEV, generator=g)
+    x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x2, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    torch.cuda.synchronize()
+    t_split = time.perf_counter() - t0
+    assert torch.equal(x, x2) and torch.isfinite(x).all()
+    for sl in (slice(0, 200), slice(B // 2 + 5, B // 2 + 77), slice(B - 130, B)):
+        xs, _ = sm.sample_ode_from_base(z[sl].contiguous(), method="rk4", options=opts)
+        assert torch.equal(xs, x[sl])
+    idx = torch.arange(0, B, B // 64)
+    ref = so64.sample_ode_from_base(z[idx].cpu().double(), None, "rk4", opts).float()
+    assert _state_err(x[idx], ref) < STATE_TOL
+    sm.precision = "f32"
+    y, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sm.sample_ode_from_base(z, method="rk4", options=opts)
+    torch.cuda.synchronize()
+    t_f32 = time.perf_counter() - t0
+    assert ((x - y).abs().max() / y.abs().max()).item() < STATE_TOL
+    print(f"\n[split] 2^20 x 100-step RK4: bf16x3 {t_split * 1e3:.1f} ms ({B / t_split:.3g} samples/s), "
+          f"f32 {t_f32 * 1e3:.1f} ms ({B / t_f32:.3g} samples/s), speed-up {t_f32 / t_split:.2f}x")
+    assert t_split < 0.8 * t_f32
