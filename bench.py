@@ -34,6 +34,7 @@ sys.path.insert(0, str(ROOT))
 DIM, UNITS, EMB = 16, [256, 256, 256, 256], 8
 N_STEPS = 100
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16: 32 cycles)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -103,6 +104,49 @@ def _record(name, units, unit, wall_s, kernel, kernel_ms, flop, note):
             "kernel_ms": kernel_ms, "launches": note.get("launches", 1), "flop_algorithmic": flop,
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS}, "dtype": "f32", **{k: v for k, v in note.items() if k != "launches"}}
+
+
+def split_precision_record(device, z, opts, steps, warmup, f32_x):
+    """The SAME workload as the headline loop on the opt-in split-precision kernels (precision="bf16x3": every fp32
+    operand cut into three bf16 parts, six bf16 MFMAs per product term, fp32 accumulate -- fp32-class accuracy).  A
+    second record beside the f32 line, never instead of it.  Two rooflines: the bf16 MFMA peak against the MFMA work
+    actually executed (6 x the algorithmic MACs), and the algorithmic (fp32-equivalent) rate for comparison with
+    the f32 line."""
+    from flowfusion_amd import _native
+    sm = build_model(device)
+    sm.precision = "bf16x3"
+    B = z.shape[0]
+    for _ in range(warmup):
+        x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+        b.record()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    n_evals = 4 * N_STEPS
+    flop_alg = 2.0 * mac_per_eval(DIM, UNITS) * n_evals * B
+    # executed: 6 bf16 MFMAs per (32-row tile, 16-wide k-step) -- first layer 1 k-step x 8 tiles, hidden 16 x 8, output
+    # 16 x 1 -- of 2 x 32 x 32 x 16 FLOP each, per 32 samples and evaluation
+    mfma_per_eval = 6 * (8 * 1 + 3 * 8 * 16 + 16)
+    flop_exec = mfma_per_eval * 32768.0 * n_evals * (B / 32)
+    err = float((x - f32_x).abs().max() / f32_x.abs().max())
+    return {
+        "metric": "samples/sec (whole node), 16-dim VP-SDE 100-step RK4", "value": B * steps / elapsed, "unit": "samples/s",
+        "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "dtype": "bf16x3-split, f32 accumulate", "precision_option": "bf16x3 (opt-in; the default and the headline are f32)",
+        "kernel": _native.kernel_name(sm._net().plan(0)), "kernel_ms_avg": kms,
+        "roofline": {"bound": "mfma", "achieved": flop_exec / (kms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flop_exec / (kms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                     "flop_executed_per_launch": flop_exec, "note": "executed bf16 MFMA FLOPs (6 products per term) vs the dense bf16 peak"},
+        "fp32_equivalent": {"achieved": flop_alg / (kms * 1e-3) / 1e12, "unit": "TFLOP/s", "flop_per_launch": flop_alg,
+                            "vs_fp32_mfma_peak": flop_alg / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+        "max_abs_diff_vs_f32_kernel_over_max_abs": err,
+    }
 
 
 def extra_configs(device):
@@ -345,6 +389,7 @@ def main():
             out["cpu_baseline_1thread"] = cb1
             torch.set_num_threads(usable_cores())
         if args.extras and world == 1:
+            out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x)
             out["extra_configs"] = extra_configs(device)
         print(json.dumps(out), flush=True)
     if world > 1:

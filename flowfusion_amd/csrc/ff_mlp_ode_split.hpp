@@ -98,6 +98,9 @@ __device__ __forceinline__ float from_value_lane(float v)
 template <bool TANGENTS>
 __device__ __forceinline__ float act1(float a, bool is_tangent)
 {
+#ifdef FF_SPLIT_NOACT           // timing experiment only: identity activation (wrong results)
+    return a;
+#endif
     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896340736f));
     const float h = a * s;
     if constexpr (!TANGENTS) return h;
@@ -266,13 +269,17 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             asm volatile("" : "+s"(rbuf));             // (periodic over evaluations as well: keep it a run-time value)
             unsigned wb = rbuf + 2 * GB;
             if (wb >= 3 * GB) wb -= 3 * GB;
+#ifndef FF_SPLIT_NODMA          // timing experiment only: never refresh the weight buffers (wrong results)
             fetch_granule(wb);                         // granule + 2 -> the buffer read before this one
+#endif
         }
         if constexpr (GQ == 7) {
             // everything but the six DMAs just issued has landed, and this wavefront's reads of the current buffer
             // have returned: after the barrier the next granule is visible to all and the previous buffer is free
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+#ifndef FF_SPLIT_NOBARRIER      // timing experiment only (with FF_SPLIT_NODMA)
             __builtin_amdgcn_s_barrier();
+#endif
             rbuf += GB;
             if (rbuf >= 3 * GB) rbuf = 0;
             wa_next = lane16 + rbuf;
@@ -362,7 +369,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 constexpr int t = decltype(tt)::value;
                 constexpr int q = s * NT + t;
                 pre(std::integral_constant<int, q % 8>{});
+#ifndef FF_SPLIT_NODMA
                 if constexpr (q == 0) fetch_c1(e + 1);                 // (after the weight DMAs of this granule)
+#endif
                 group6(A[t], w, yf[s]);
                 if constexpr (s == K1S - 1) {                           // tile 0 is complete: its activation rides here
                     if constexpr (t == 1) {
