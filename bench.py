@@ -384,12 +384,21 @@ def main():
             lp = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
             lp_ref = so.log_prob(xq, None, "rk4", opts, "hutch", sm.e.cpu())
             out["log_prob_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+            if args.extras:     # the same check on the split-precision kernels (same points, same probe)
+                sm.precision = "bf16x3"
+                torch.manual_seed(99)
+                assert torch.equal(torch.randn(128, DIM) * 0.9, xq)
+                lps = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
+                split_lp_err = float(((lps - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+                sm.precision = "f32"
             sm.hutch = False
             _, _, cb1 = cpu_baseline(sm, 2048, opts, budget_s=10.0, threads=1)
             out["cpu_baseline_1thread"] = cb1
             torch.set_num_threads(usable_cores())
         if args.extras and world == 1:
             out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x)
+            if args.cpu_batch > 0:
+                out["split_precision_record"]["log_prob_rel_err"] = split_lp_err
             out["extra_configs"] = extra_configs(device)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -100,6 +100,12 @@ FF_HD constexpr int chunk_block(const LayerGeom& L, int c)
     return c < L.GA * L.NOB ? c % L.NOB : (c - L.GA * L.NOB) / L.GB;
 }
 
+// (group, logical output block) -> chunk index: the inverse of chunk_group / chunk_block
+FF_HD constexpr int chunk_index(const LayerGeom& L, int g, int ob)
+{
+    return g < L.GA ? g * L.NOB + ob : L.GA * L.NOB + ob * L.GB + (g - L.GA);
+}
+
 struct Layout {
     int tile;     // 32 or 16
     int H;        // hidden width on chip (multiple of 32)

@@ -408,10 +408,17 @@ FF_HD constexpr int act_group_at(const LayerGeom& L, int phys, int gpb, int M, i
     return blk <= L.NOB - 2 ? blk * gpb + gi : -1;
 }
 
-template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, bool GENERIC_ACT = false>
+// COOP (small batches): the four wavefronts of a workgroup share ONE tile of TILE columns and split every hidden layer's
+// output rows between them (NB / 4 logical blocks each), exchanging the activations through LDS after each layer --
+// one evaluation then takes about a third of a lone wavefront's time, which is what counts when the batch is too small
+// to give every SIMD a tile of its own.  Same packed weights, same fp32 FMA chains in the same order (results equal the
+// one-wavefront kernel's bit for bit); state, stage slots and bookkeeping are replicated in the four wavefronts and
+// wavefront 0 writes the outputs.  The launcher picks the twin by batch size (ff_api.cpp).
+template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, bool GENERIC_ACT = false, bool COOP = false>
 __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args)
 {
     static_assert(kChunkPad % RING == 0, "ring must divide the chunk padding");
+    static_assert(!COOP || (H / 32) % 4 == 0, "the cooperative twin splits the blocks of a layer four ways");
     typedef Tile<TILE> T;
     constexpr int NB = H / 32;                       // logical blocks per hidden layer
     constexpr int RB = T::RB;                        // registers per logical block
@@ -427,7 +434,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const int col = lane & (TILE - 1);
     const int lane16 = lane * 16;
     const int q16 = qd * 16;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // tile index: one per wavefront, or one per workgroup in the cooperative twin
+    const long long wave = COOP ? (long long)blockIdx.x : (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wavefront of the workgroup
     const int D = args.dim;
     const int C = args.cond_dim;
     const ActSpec aspec = {args.act_kind, args.act_p0, args.act_p1};
@@ -491,7 +500,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     // Runge-Kutta stage slots k[s] live in LDS (each lane only ever touches its own words,
     // so no barrier is needed); this keeps 6*DREGS registers free for the weight pipeline.
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_slots[];
-    f32x4* const ks = lds_slots + (size_t)(threadIdx.x >> 6) * kSlots * R4 * 64 + lane;
+    // (cooperative twin: one copy -- the four wavefronts hold the same tile and write the same values)
+    f32x4* const ks = lds_slots + (size_t)(COOP ? 0 : (threadIdx.x >> 6)) * kSlots * R4 * 64 + lane;
+    f32x4* const exch = lds_slots + (size_t)kSlots * R4 * 64 + lane;         // COOP: 2 x (KH / 4) x 64 exchange slots
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
@@ -525,21 +536,37 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const int out_sbyte = L.chunk_off_out() * CB;
     const int out_bias_byte = (int)(L.bias_off_out() * 4);
 
-    // prefetch ring: the first RING chunks of layer 1
+    // ---- cooperative twin: this wavefront's share of a layer --------------------------------------------------------
+    // Wavefront wv owns logical blocks [wv * NBW, (wv + 1) * NBW) of every hidden layer and visits its chunks of a layer
+    // group-major: visit i = (group i / NM, own block i % NM) -> chunk_index() of ff_layout.h in the SAME packed stream.
+    // Every layer's visiting list is padded to a multiple of RING, so a layer always starts at ring slot 0.
+    constexpr int NBW = COOP ? NB / 4 : NB;
+    const int ob0 = wv * NBW;
+    constexpr LayerGeom CG1 = layer_geom(K1, NB, RB / 4), CGH = layer_geom(KH, NB, RB / 4), CGO = layer_geom(KH, NOB_OUT, RB / 4);
+    constexpr int CN1 = (CG1.G * NBW + RING - 1) / RING * RING;          // padded visits of layer 1
+    auto coop_byte = [&](const LayerGeom& G, int sbyte, int i, int nm, int b0) __attribute__((always_inline)) {
+        const int g = i / nm, j = i % nm;
+        return sbyte + chunk_index(G, g < G.G ? g : 0, b0 + j) * CB;      // (padding visits re-read a real chunk)
+    };
+
+    // prefetch ring: the first RING chunks of layer 1 (of this wavefront's visiting list in the cooperative twin)
     f32x4 ring[RING][T::PHYS];
 #pragma unroll
     for (int i = 0; i < RING; ++i)
 #pragma unroll
-        for (int p = 0; p < T::PHYS; ++p) ring[i][p] = sload(ws, lane16, i * CB + p * 1024);
+        for (int p = 0; p < T::PHYS; ++p)
+            ring[i][p] = sload(ws, lane16, (COOP ? coop_byte(CG1, 0, i, NBW, ob0) : i * CB) + p * 1024);
 
     float P[KH];
     // Accumulators of the hidden layers.  They always hold the bias of the layer about to run: a block is
     // refilled with the next layer's bias (straight from the bias stream, in accumulator order) as soon as its
     // pre-activations have been consumed, so the MFMA chain adds the bias and the activation path does not.
     // Tangent lanes fetch through an out-of-range offset (q16b) and start from zero.
-    BlockAcc<TILE> hacc[NB];
+    BlockAcc<TILE> hacc[COOP ? 1 : NB];
+    if constexpr (!COOP) {
 #pragma unroll
-    for (int o = 0; o < NB; ++o) hacc[o] = load_bias_acc<TILE>(ts, q16b, 128 + o * 128);
+        for (int o = 0; o < NB; ++o) hacc[o] = load_bias_acc<TILE>(ts, q16b, 128 + o * 128);
+    }
 #ifdef FF_DEBUG_STAMPS
     int stamp_n = 0;
     const bool stamp_on = (blockIdx.x == 0 && threadIdx.x == 0 && args.debug_stamps != nullptr);
@@ -584,6 +611,126 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #else
         auto dbg = []() {};
 #endif
+        float net[NOB_OUT * RB];
+        if constexpr (COOP) {
+            // ---- cooperative evaluation: NB / 4 blocks of every layer per wavefront, activations exchanged through LDS --
+            constexpr int RBQ = RB / 4;
+            const int c1_byte = row_byte + 128, c1_next = row_byte + args.etab_stride * 4 + 128;
+            // one layer of this wavefront's share: acc[j] += W[block b0 + j, :] . Bop over the layer's groups, in
+            // ascending group order (the order of the one-wavefront kernel: same FMA chain per output row).
+            // next(k, slot): request visit k of the NEXT layer into ring slot `slot`.
+            auto coop_layer = [&](auto tag, const auto& Bop, auto& acc, int sbyte, int b0, auto&& next) __attribute__((always_inline)) {
+                constexpr int KIND = decltype(tag)::value;          // 0 = layer 1, 1 = hidden, 2 = output
+                constexpr LayerGeom G = KIND == 0 ? CG1 : (KIND == 1 ? CGH : CGO);
+                constexpr int NM = KIND == 2 ? NOB_OUT : NBW;
+                constexpr int NV = KIND == 0 ? CN1 : G.G * NM;
+                static_assert(NV % RING == 0, "visiting lists are multiples of the ring length");
+                constexpr int OUT_LAST = (DREGS * T::NQ - (NOB_OUT - 1) * 32 + TILE - 1) / TILE;
+                constexpr int LAST_PHYS = KIND == 2 ? (OUT_LAST < T::PHYS ? OUT_LAST : T::PHYS) : T::PHYS;
+                static_for<NV>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    constexpr int slot = i % RING, g = i / NM, j = i % NM;
+                    if constexpr (g < G.G) {
+                        static_for<4>([&](auto qq) {
+                            constexpr int q = decltype(qq)::value;
+                            static_for<T::PHYS>([&](auto pp) {
+                                constexpr int p = decltype(pp)::value;
+                                if constexpr (KIND == 2 && j == NM - 1 && p >= LAST_PHYS) {
+                                    if constexpr (g == 0 && q == 0) acc[j].v[p] = T::zero();
+                                } else if constexpr (KIND == 2 && g == 0 && q == 0)
+                                    acc[j].v[p] = T::mfma(ring[slot][p][q], Bop[4 * g + q], T::zero());
+                                else
+                                    acc[j].v[p] = T::mfma(ring[slot][p][q], Bop[4 * g + q], acc[j].v[p]);
+                            });
+                        });
+                    }
+                    constexpr int nxt = i + RING;
+                    if constexpr (nxt < NV) {
+                        static_for<T::PHYS>([&](auto pp) {
+                            constexpr int p = decltype(pp)::value;
+                            ring[slot][p] = sload(ws, lane16, coop_byte(G, sbyte, nxt, NM, b0) + p * 1024);
+                        });
+                    } else {
+                        next(std::integral_constant<int, nxt - NV>{}, std::integral_constant<int, slot>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400 | 0x80);
+                });
+            };
+            // activate this wavefront's blocks and trade them for everybody else's: P <- all KH operand registers
+            auto coop_exchange = [&](const BlockAcc<TILE> (&acc)[NBW], int buf) __attribute__((always_inline)) {
+                f32x4* const xb = exch + (size_t)buf * (KH / 4) * 64;
+                static_for<NBW>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    static_for<RBQ>([&](auto rr) {
+                        constexpr int r4 = decltype(rr)::value;
+                        ActGroup ag;
+                        float out[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ag.pre[i] = acc[j].reg(4 * r4 + i);
+                        static_for<kActStages>([&](auto kk) {
+                            act_stage<TANGENTS, GENERIC_ACT, decltype(kk)::value>(ag, out, is_tangent, value_lane_bytes, aspec);
+                        });
+                        xb[((ob0 + j) * RBQ + r4) * 64] = f32x4{out[0], out[1], out[2], out[3]};
+                    });
+                });
+                __syncthreads();
+#pragma unroll
+                for (int k4 = 0; k4 < KH / 4; ++k4) {
+                    const f32x4 v = xb[k4 * 64];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) P[4 * k4 + i] = v[i];
+                }
+            };
+            auto next_hidden_or_out = [&](int l_next, auto kk, auto sl) __attribute__((always_inline)) {
+                // visit k of the layer after a hidden-side layer: hidden layer l_next, or the output layer
+                constexpr int k = decltype(kk)::value, slot = decltype(sl)::value;
+                const bool is_hid = l_next < args.n_hidden - 1;
+                const int byte = is_hid ? coop_byte(CGH, L.chunk_off_hid(l_next) * CB, k, NBW, ob0)
+                                        : coop_byte(CGO, out_sbyte, k, NOB_OUT, 0);
+                static_for<T::PHYS>([&](auto pp) {
+                    constexpr int p = decltype(pp)::value;
+                    ring[slot][p] = sload(ws, lane16, byte + p * 1024);
+                });
+            };
+            BlockAcc<TILE> cacc[NBW];
+            int xbuf = 0;
+            // layer 1
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) cacc[j] = load_bias_acc<TILE>(ts, q16b, c1_byte + (ob0 + j) * 128);
+            coop_layer(std::integral_constant<int, 0>{}, y, cacc, 0, ob0,
+                       [&](auto kk, auto sl) { next_hidden_or_out(0, kk, sl); });
+            for (int l = 0; l < args.n_hidden - 1; ++l) {
+                BlockAcc<TILE> nacc[NBW];                            // this layer's bias: requested before the exchange
+                const int bbyte = (int)(L.bias_off_hid(l) * 4);
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) nacc[j] = load_bias_acc<TILE>(ws, q16b, bbyte + (ob0 + j) * 128);
+                coop_exchange(cacc, xbuf);
+                xbuf ^= 1;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) cacc[j] = nacc[j];
+                coop_layer(std::integral_constant<int, 1>{}, P, cacc, L.chunk_off_hid(l) * CB, ob0,
+                           [&](auto kk, auto sl) { next_hidden_or_out(l + 1, kk, sl); });
+            }
+            BiasBlk<TILE> obias[NOB_OUT];
+#pragma unroll
+            for (int o = 0; o < NOB_OUT; ++o) obias[o] = load_bias<TILE>(ws, q16b, out_bias_byte + o * 128);
+            coop_exchange(cacc, xbuf);
+            // output layer: every wavefront computes all of it (a handful of rows; no exchange, and the same chain as the
+            // one-wavefront kernel); the ring moves on to layer 1 of the next evaluation
+            BlockAcc<TILE> oacc[NOB_OUT];
+            coop_layer(std::integral_constant<int, 2>{}, P, oacc, out_sbyte, 0, [&](auto kk, auto sl) {
+                constexpr int k = decltype(kk)::value, slot = decltype(sl)::value;
+                static_for<T::PHYS>([&](auto pp) {
+                    constexpr int p = decltype(pp)::value;
+                    ring[slot][p] = sload(ws, lane16, coop_byte(CG1, 0, k, NBW, ob0) + p * 1024);
+                });
+            });
+#pragma unroll
+            for (int o = 0; o < NOB_OUT; ++o)
+#pragma unroll
+                for (int r = 0; r < RB; ++r) net[o * RB + r] = oacc[o].reg(r) + obias[o].reg(r);
+            (void)c1_next;
+        } else {
         // `pend` = pre-activations of the previous layer's last block; they
         // are activated into P[(NB-1)*RB ..] behind the first MFMAs of the next layer, whose
         // phase A does not read the last k-block.
@@ -663,7 +810,6 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 [&](const BlockAcc<TILE>& acc) { park_and_refill(ws, nbyte, acc); }, dbg);
         }
         // ---- output layer ----------------------------------------------------------------
-        float net[NOB_OUT * RB];
         // the hidden accumulators are idle from here to the next evaluation's first layer: fetch its c1 now
         // (a row past the table reads as zeros)
 #pragma unroll
@@ -697,6 +843,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                     net[(NOB_OUT - 1) * RB + r] = acc.reg(r) + bias[(NOB_OUT - 1) & 1].reg(r);
             },
             dbg);
+        }   // !COOP
 
         // ---- RHS and stage bookkeeping -----------------------------------------------------
         float rhs[DREGS];
@@ -708,7 +855,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             div = is_tangent ? __builtin_fmaf(a_e, ee, b_e * dot) : 0.f;
             // full Jacobian of the last evaluation's right-hand side (unit tangents): tangent column j holds
             // d rhs / d y_j = a_e e_j + b_e dNET/dy_j; stored as row j of jac_out[sample]
-            if (args.jac_out && e == args.n_evals - 1 && is_tangent && col_live) {
+            if (args.jac_out && e == args.n_evals - 1 && is_tangent && col_live && (!COOP || wv == 0)) {
                 const int tj = args.tangent_first + role - 1;
                 float* jp = args.jac_out + ((size_t)sample * D + tj) * D;
 #pragma unroll
@@ -777,7 +924,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         }
         return tot;
     };
-    const bool writer = col_live && !is_tangent;
+    const bool writer = col_live && !is_tangent && (!COOP || wv == 0);
     float lp0 = 0.f;
     if constexpr (TANGENTS) {
         if (args.dlogp_in) lp0 = args.dlogp_in[sample];
@@ -820,7 +967,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         });
     }
     bool bad = false;
-    if (col_live && !is_tangent) {
+    if (writer) {
 #pragma unroll
         for (int r = 0; r < DREGS; ++r) {
             const int d = feat_of_reg(TILE, r, qd);

@@ -18,6 +18,7 @@ struct KernelEntry {
     int any_act;    // 0: SiLU compiled in; 1: activation selected at run time (FF_ACT_*)
     LaunchFn launch;
     const char* name;
+    LaunchFn launch_coop;   // cooperative twin for small batches (one tile per workgroup, ff_mlp_ode.hpp COOP) or NULL
 };
 
 // defined in the generated ff_table.cpp
