@@ -191,7 +191,26 @@ def extra_configs(device):
                        Be, "log-probs/s", wall, name_of(net, 2), kms, (DIM + 1) * 2.0 * mac_per_eval(DIM, UNITS) * tab2.shape[0] * Be,
                        {"launches": len(passes), "note": "kernel_ms sums the launches; columns carried: "
                         + " + ".join(f"(1+{c})" for _, c in passes) + f" for {DIM}+1 needed"}))
-    del sm, net, x0, xe
+    # --- small batches: one solve of config 2 at 4096 samples (latency-bound: 256 tiles for 1024 SIMDs) -----------------
+    # default dispatch = the cooperative twin (a tile per workgroup); FF_COOP=0 pins the one-wavefront kernel
+    sm.hutch = False
+    zs = x0[:4096].contiguous()
+    fwd = {"step_size": (1.0 - eps) / N_STEPS}
+    lat = {}
+    for pin in (None, "0"):
+        if pin is None:
+            os.environ.pop("FF_COOP", None)
+        else:
+            os.environ["FF_COOP"] = pin
+        sm.sample_ode_from_base(zs, method="rk4", options=fwd)
+        lat[pin] = min(_timed(lambda: sm.sample_ode_from_base(zs, method="rk4", options=fwd), device)[1] for _ in range(3))
+    os.environ.pop("FF_COOP", None)
+    out.append({"workload": "small batch: BASELINE configs[1] model, 100-step RK4, batch 4096 (latency of ONE solve)",
+                "value": 4096 / lat[None], "unit": "samples/s", "wall_ms": 1e3 * lat[None],
+                "wall_ms_one_wavefront_kernel": 1e3 * lat["0"], "speedup_of_cooperative_twin": lat["0"] / lat[None],
+                "dtype": "f32", "note": "below ~3/4 of a chip's worth of tiles the launcher gives each tile to a workgroup "
+                "(rows of a layer split over its 4 wavefronts, LDS exchange per layer); bitwise the same results"})
+    del sm, net, x0, xe, zs
     # --- config 4: 64-dim flow matching, 5x512, 200 fixed Dormand-Prince steps, 2^22 / 8 GPUs = 2^19 per GPU ------
     torch.manual_seed(0)
     f = Fm.ODEFlow(64, [512] * 5).to(device).eval()

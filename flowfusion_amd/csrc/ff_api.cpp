@@ -418,7 +418,8 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     // in about a third of the time.  Same packed weights, bitwise the same results.  FF_COOP=0 / 1 pins the choice.
     const long long spt = plan->tile / (1 + nt);           // samples per tile
     const long long tiles = (a->batch + spt - 1) / spt;
-    bool coop = k.launch_coop != nullptr && tiles <= 512;
+    // (two workgroups of a <= 256-wide twin share a CU: it still wins at three quarters of a chip's worth of tiles)
+    bool coop = k.launch_coop != nullptr && tiles <= (plan->width <= 256 ? 768 : 512);
     if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
     const long long grid = coop ? tiles : (tiles + 3) / 4;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;

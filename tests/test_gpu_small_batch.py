@@ -1,0 +1,123 @@
+"""GPU tier: the cooperative (small-batch) twins of the f32 kernels.  Below about half a chip's worth of tiles the
+launcher hands a batch to a kernel that gives each tile to a whole WORKGROUP (the rows of every layer split over its
+four wavefronts, activations exchanged through LDS) instead of one wavefront.  It uses the same packed weights and
+performs the same fp32 FMA chains in the same order, so the results must equal the one-wavefront kernel's BIT FOR BIT
+-- in every mode (state, Hutchinson, exact trace, Euler-Maruyama, adaptive steps, Jacobian output), for every
+kernel layout that has a twin.  FF_COOP=0 / 1 pins the choice per launch."""
+import pytest
+import torch
+
+from tests.test_gpu_parity import DEV, _seeded_score_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(built_library):
+    assert torch.cuda.is_available(), "the gpu tier needs a GPU"
+
+
+def _both(monkeypatch, fn):
+    out = []
+    for pin in ("0", "1"):
+        monkeypatch.setenv("FF_COOP", pin)
+        out.append(fn())
+    monkeypatch.delenv("FF_COOP")
+    return out
+
+
+SHAPES = [
+    (16, 0, [256] * 4, "VPSDE", True),          # 16x16x4, two waves per SIMD (BASELINE config 2)
+    (2, 0, [128] * 3, "VESDE", False),          # the demo notebook's network: 32x32x2, width 128
+    (32, 8, [256] * 4, "VESDE", False),         # BASELINE config 5 shape
+    (5, 3, [128, 100], "SUBVPSDE", False),      # ragged widths, conditional
+    (40, 0, [512, 300], "VPSDE", True),         # 512-wide kernels
+    (16, 0, [256], "VPSDE", True),              # a single hidden layer
+]
+
+
+@pytest.mark.parametrize("D,C,units,sde,no_sigma", SHAPES)
+def test_cooperative_twin_is_bitwise_the_one_wavefront_kernel(D, C, units, sde, no_sigma, monkeypatch):
+    sm, so32, _ = _seeded_score_model(D, C, units, sde, no_sigma, 7)
+    B = 77
+    torch.manual_seed(1)
+    base = torch.randn(B, D, device=DEV)
+    cond = torch.randn(B, C, device=DEV) if C else None
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 12}
+    a, b = _both(monkeypatch, lambda: sm.sample_ode_from_base(base, conditional=cond, method="rk4", options=opts)[0])
+    assert torch.equal(a, b)
+    # and the oracle agrees (the twin is a kernel of its own, not just a consistent one)
+    ref = so32.sample_ode_from_base(base.cpu(), None if cond is None else cond.cpu(), "rk4", opts)
+    assert ((b.cpu() - ref).abs().max() / ref.abs().max()).item() < 2e-5
+    # Hutchinson: value / tangent column pairs
+    sm.hutch = True
+    net = sm._net()
+    e = torch.sign(torch.randn(B, D, device=DEV))
+    tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), "dopri5_fixed", opts, 1)
+    r0, r1 = _both(monkeypatch, lambda: net.integrate(base * 0.5, tab, 1, cond=cond, probe=e))
+    assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+    # exact trace (unit tangents, several passes when D + 1 exceeds the tile)
+    sm.hutch = False
+    l0, l1 = _both(monkeypatch, lambda: sm.log_prob(base[:20] * 0.5, conditional=None if cond is None else cond[:20],
+                                                    method="euler", options=opts))
+    assert torch.equal(l0, l1)
+    # Euler-Maruyama with a noise buffer and with the in-kernel stream
+    noise = torch.randn(9, B, D, device=DEV)
+    def em():
+        it = iter(noise)
+        return sm._sample_sde_from(base, lambda like: next(it), cond, steps=9)
+    s0, s1 = _both(monkeypatch, em)
+    assert torch.equal(s0, s1)
+    p0, p1 = _both(monkeypatch, lambda: sm._sample_sde_from(base, None, cond, 9, rng=(5, 100)))
+    assert torch.equal(p0, p1)
+
+
+def test_cooperative_twin_adaptive_and_jacobian(monkeypatch):
+    sm, _, _ = _seeded_score_model(4, 0, [128, 128], "VESDE", False, 51)
+    torch.manual_seed(8)
+    base = torch.randn(300, 4, device=DEV)
+    a, b = _both(monkeypatch, lambda: sm.sample_ode_from_base(base)[0])                   # dopri5: one launch per attempt
+    assert torch.equal(a, b)
+    x0 = torch.randn(64, 4, device=DEV) * 0.5
+    l0, l1 = _both(monkeypatch, lambda: sm.log_prob(x0))                                   # adaptive + exact trace
+    assert torch.equal(l0, l1)
+    sm.hutchpp, sm.hpp_rank = True, 4                                                       # Jacobian output path
+    torch.manual_seed(3)
+    j0 = None
+    outs = []
+    for pin in ("0", "1"):
+        monkeypatch.setenv("FF_COOP", pin)
+        torch.manual_seed(3)
+        outs.append(sm.log_prob(x0, method="rk4", options={"step_size": 0.25}))
+    monkeypatch.delenv("FF_COOP")
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_small_batches_take_the_twin_by_default_and_are_faster():
+    """Default dispatch: at 2048 samples (128 tiles of 16) the launcher takes the cooperative twin; one 100-step RK4
+    solve must take well under the one-wavefront kernel's time (measured with FF_COOP=0)."""
+    import os
+    import time
+    sm, _, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 17)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 100}
+    z = torch.randn(2048, 16, device=DEV)
+
+    def timed():
+        sm.sample_ode_from_base(z, method="rk4", options=opts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
+        torch.cuda.synchronize()
+        return x, time.perf_counter() - t0
+
+    assert "FF_COOP" not in os.environ
+    x_def, t_def = timed()
+    os.environ["FF_COOP"] = "0"
+    try:
+        x_one, t_one = timed()
+    finally:
+        del os.environ["FF_COOP"]
+    assert torch.equal(x_def, x_one)
+    print(f"\n[small batch] 2048 x 100-step RK4: default {t_def * 1e3:.2f} ms, one-wavefront kernel {t_one * 1e3:.2f} ms "
+          f"({t_one / t_def:.2f}x)")
+    assert t_def < 0.6 * t_one
