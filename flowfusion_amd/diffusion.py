@@ -27,7 +27,7 @@ import torch
 from torch import nn
 from torch.distributions import Normal
 
-from . import adaptive, solvers
+from . import adaptive, generic, solvers
 from . import host_stepper, trace_estimators
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
 
@@ -255,6 +255,29 @@ class ScoreModel(nn.Module):
             O = trace_estimators.draw_probes(mx, x)
         return trace_estimators.xtrace(A, O.to(A.device))
 
+    # -- any other `model=` module: native stepping around the module's own forward (generic.py) -------------
+    def _fusable(self) -> bool:
+        """The score network is the reference's MLP (weights the fused kernels can hold)."""
+        m = self.model
+        return hasattr(m, "NN") and hasattr(m, "W") and hasattr(m, "pi") and hasattr(m, "n_dimensions")
+
+    def _rhs_module(self, t, y):
+        """ODE right-hand side through ``self.forward`` (the reference's own RHS, diffusion.py:281-508): the user's
+        module evaluates the score; divergences come from autograd exactly as in the reference."""
+        if not self.prob:
+            return self.forward(t, (y,)), None
+        xdot, div = self.forward(t, (y, None))
+        return xdot, div.reshape(-1)
+
+    def _solve_generic(self, x, t_span, method, options, mode, atol, rtol, affine):
+        if affine.get("in_shift") is not None:
+            x = (x - affine["in_shift"]) / affine["in_scale"]
+        y, lp, stats = generic.solve(self._rhs_module, x, t_span, method, options, mode != MODE_STATE, atol, rtol)
+        self.last_solver_stats = stats
+        if affine.get("out_scale") is not None:
+            y = y * affine["out_scale"] + affine["out_shift"]
+        return y, lp
+
     # -- fused path -----------------------------------------------------------------------------
     def _net(self) -> FusedNet:
         m = self.model
@@ -320,6 +343,8 @@ class ScoreModel(nn.Module):
         fixed-grid methods as one launch, ``dopri5`` as one launch per attempted step.  ``affine``
         (in_shift / in_scale / out_scale / out_shift, the PopulationModel wrappers' pre- and post-processing)
         rides in the kernel's prologue / epilogue on fixed grids and is applied around the adaptive loop."""
+        if not self._fusable():
+            return self._solve_generic(x, t_span, method, options, mode, atol, rtol, affine)
         net = self._net()
         if method == "dopri5":
             if affine.get("in_shift") is not None:
@@ -389,6 +414,14 @@ class ScoreModel(nn.Module):
         standard-normal slab (tests inject the reference's captured stream here); with
         ``rng = (seed, global index of row 0)`` the kernel draws the normals itself.  The steps run in as few
         launches as the noise memory and the progress granularity allow (one, normally)."""
+        if not self._fusable():
+            if rng is not None:
+                raise NotImplementedError("noise='philox' lives in the fused kernel; a custom score module samples with noise='torch'")
+            host = copy.deepcopy(self.sde).to("cpu")
+            drift = lambda t, xx: self.sde.drift(t, xx) - self.sde.diffusion(t, xx) ** 2 * self.score(t, xx, conditional=conditional)
+            g_of_t = lambda ts: host.diffusion(ts, torch.ones(ts.numel(), 1))
+            return generic.euler_maruyama(drift, g_of_t, x, draw, torch.as_tensor(self.sde.T, dtype=torch.float32).cpu(),
+                                          self.sde.epsilon.detach().cpu(), steps, progress)
         net = self._net()
         if x.dim() != 2:
             raise NotImplementedError("sample_sde: only [batch, dim] states are supported")
@@ -505,7 +538,8 @@ class ScoreModel(nn.Module):
         """sample_ode_from_base proper; ``x * out_scale + out_shift`` (PopulationModel*.forward,
         diffusion.py:1575-1585, 1772-1784) is applied by the kernel's epilogue."""
         self._check_inputs(base_samples, "sample_ode_from_base")
-        self._net()
+        if self._fusable():
+            self._net()
         z = base_samples * self.sde.sigma_max if hasattr(self.sde, "sigma_max") else base_samples
         self.prob = False
         self.conditional = conditional
@@ -525,13 +559,27 @@ class ScoreModel(nn.Module):
     def _solve_forward(self, x0_samples, conditional, atol, rtol, method, options, in_shift=None, in_scale=None):
         """solve_odes_forward proper; ``(x - in_shift) / in_scale`` (PopulationModel*.log_prob,
         diffusion.py:1633, 1837) is applied by the kernel's prologue."""
-        self._net()
+        fused = self._fusable()
+        if fused:
+            self._net()
         self.prob = True
         self.conditional = conditional
         if (self.hutchpp or self.xtrace) and not self.hutch:
             if in_shift is not None:
                 x0_samples = (x0_samples - in_shift) / in_scale
-            return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options)
+            if fused:
+                return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options)
+            # any other module: forward() runs the estimator itself (reverse mode, like the reference); the probes are
+            # drawn once per solve on the state's device (:703-719)
+            (r, m), mx = self._probe_counts(x0_samples.shape[1])
+            if self.hutchpp:
+                self.S = trace_estimators.draw_probes(r, x0_samples)
+                self.G = trace_estimators.draw_probes(m, x0_samples)
+            else:
+                self.O = trace_estimators.draw_probes(mx, x0_samples)
+            t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
+            xT, dlogp = self._solve_generic(x0_samples, t_span, method, options, MODE_EXACT, atol, rtol, {})
+            return xT, dlogp.view(-1, 1)
         probe = None
         mode = MODE_EXACT
         if self.hutch:
