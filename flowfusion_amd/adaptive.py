@@ -46,6 +46,31 @@ ORDER = 5
 SAFETY, IFACTOR, DFACTOR = 0.9, 10.0, 0.2
 
 
+class EmbeddedTableau:
+    """An embedded explicit Runge-Kutta pair with the first-same-as-last property, as torchdiffeq's
+    ``_ButcherTableau`` + ``c_mid`` + ``order``: stage i+1 at ``t0 + alpha[i] dt`` on ``y0 + dt sum_j beta[i][j] k_j``;
+    the last stage is evaluated at (t1, y1), so it is the next step's first stage."""
+
+    def __init__(self, name, order, alpha, beta, c_sol, c_error, c_mid):
+        self.name, self.order = name, order
+        self.alpha, self.beta, self.c_sol, self.c_error, self.c_mid = alpha, beta, c_sol, c_error, c_mid
+        self.stages = len(c_sol)                      # including the FSAL stage
+
+
+TABLEAUX = {
+    "dopri5": EmbeddedTableau("dopri5", 5, ALPHA, BETA, C_SOL, C_ERROR, C_MID),
+    # Bogacki-Shampine 3(2) (torchdiffeq bosh3.py)
+    "bosh3": EmbeddedTableau("bosh3", 3, (1 / 2, 3 / 4, 1.0), ((1 / 2,), (0.0, 3 / 4), (2 / 9, 1 / 3, 4 / 9)),
+                             (2 / 9, 1 / 3, 4 / 9, 0.0), (2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8),
+                             (0.0, 0.5, 0.0, 0.0)),
+    # Fehlberg 2(1) (torchdiffeq fehlberg2.py)
+    "fehlberg2": EmbeddedTableau("fehlberg2", 2, (1 / 2, 1.0), ((1 / 2,), (1 / 256, 255 / 256)),
+                                 (1 / 512, 255 / 256, 1 / 512), (-1 / 512, 0.0, 1 / 512), (0.0, 0.5, 0.0)),
+    # Heun-Euler 2(1) (torchdiffeq adaptive_heun.py)
+    "adaptive_heun": EmbeddedTableau("adaptive_heun", 2, (1.0,), ((1.0,),), (0.5, 0.5), (0.5, -0.5), (0.5, 0.0)),
+}
+
+
 def _f32(v) -> torch.Tensor:
     return torch.as_tensor(v, dtype=torch.float32)
 
@@ -75,12 +100,16 @@ class Dopri5:
     """Batch-global adaptive Dormand-Prince over an increasing solver-time span [t0, t1]."""
 
     def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None,
-                 norm_only=()):
+                 norm_only=(), method: str = "dopri5"):
         """``norm_only``: components the reference carries in the tuple state with a zero derivative (the raw
         ``conditional`` of ConditionalODEFlow, flow.py:779-796, 855-881).  Under the mixed norm they can only
         matter where the state itself is measured -- d0 of the initial step; their derivative and error
         estimate are identically zero."""
         opts = dict(options or {})
+        if method not in TABLEAUX:
+            raise NotImplementedError(f"adaptive method {method!r}: supported {sorted(TABLEAUX)} (dopri8 needs 13 stage "
+                                      "slots; the fused kernels keep 7 on chip)")
+        self.tab = TABLEAUX[method]
         self.norm_only = [c for c in norm_only if c is not None and c.numel() > 0]
         self.step = step
         self.has_lp = has_lp
@@ -109,17 +138,19 @@ class Dopri5:
 
     def _attempt(self, t0, dt, t1, y, lp, f0, fl0):
         """Stages 2..7 of one step from (t0, y) with step dt; returns y1, lp1, f1, fl1, mids, errors."""
+        tab = self.tab
+        S = tab.stages
         t0f, dtf, t1f = _f32(t0), _f32(dt), _f32(t1)              # time enters the stages in the state dtype
-        ts = torch.stack([t1f if a == 1.0 else t0f + a * dtf for a in ALPHA])
-        cin = torch.zeros(6, 8)
-        for i, beta in enumerate(BETA):
+        ts = torch.stack([t1f if a == 1.0 else t0f + a * dtf for a in tab.alpha])
+        cin = torch.zeros(S - 1, 8)
+        for i, beta in enumerate(tab.beta):
             cin[i, : len(beta)] = _f32(beta) * dtf
         tail = torch.zeros(4, 8)
-        tail[0, :7] = dtf * _f32(C_SOL)                            # y1    = y + dt * k . c_sol
-        tail[1] = _onehot(6)                                       # f1    = k[6]
-        tail[2, :7] = dtf * _f32(C_MID)                            # y_mid = y + dt * k . c_mid
-        tail[3, :7] = dtf * _f32(C_ERROR)                          # err   = dt * k . c_error
-        aux, aux_lp = self.step(y, f0, lp, fl0, ts, cin, torch.arange(1, 7, dtype=torch.int32), tail, 0b0101, 4)
+        tail[0, :S] = dtf * _f32(tab.c_sol)                        # y1    = y + dt * k . c_sol
+        tail[1] = _onehot(S - 1)                                   # f1    = the last stage (FSAL)
+        tail[2, :S] = dtf * _f32(tab.c_mid)                        # y_mid = y + dt * k . c_mid
+        tail[3, :S] = dtf * _f32(tab.c_error)                      # err   = dt * k . c_error
+        aux, aux_lp = self.step(y, f0, lp, fl0, ts, cin, torch.arange(1, S, dtype=torch.int32), tail, 0b0101, 4)
         if self.has_lp:
             return aux, aux_lp
         return aux, None
@@ -140,7 +171,7 @@ class Dopri5:
         if d1 <= 1e-15 and d2 <= 1e-15:
             h1 = max(1e-6, h0 * 1e-3)
         else:
-            h1 = (0.01 / max(d1, d2)) ** (1.0 / float(ORDER))      # called with order - 1 = 4 -> 1/(4+1)
+            h1 = (0.01 / max(d1, d2)) ** (1.0 / float(self.tab.order))      # called with order - 1 -> 1/((order-1)+1)
         return min(100 * h0, abs(h1))
 
     def _error_ratio(self, errs, y0s, y1s):
@@ -150,14 +181,13 @@ class Dopri5:
             parts.append(e / tol)
         return _mixed_norm(parts)
 
-    @staticmethod
-    def _optimal_step_size(last_step, error_ratio):
+    def _optimal_step_size(self, last_step, error_ratio):
         if error_ratio != error_ratio:          # NaN propagates (torch.min/max do), the next attempt raises
             return float("nan")
         if error_ratio == 0:
             return last_step * IFACTOR
         dfactor = 1.0 if error_ratio < 1 else DFACTOR
-        factor = min(IFACTOR, max(SAFETY / error_ratio ** (1.0 / ORDER), dfactor))
+        factor = min(IFACTOR, max(SAFETY / error_ratio ** (1.0 / self.tab.order), dfactor))
         return last_step * factor
 
     # -- driver ----------------------------------------------------------------------------------

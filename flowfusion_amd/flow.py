@@ -77,7 +77,7 @@ class _FlowBase(nn.Module):
 
     def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, raw_cond=None, **affine):
         net = self._net()
-        if method == "dopri5":
+        if method in solvers.NATIVE_ADAPTIVE:
             if any(v is not None for v in affine.values()):
                 raise AssertionError("affine epilogues are applied by the caller on the adaptive path")
             t = t_span.double()
@@ -86,7 +86,7 @@ class _FlowBase(nn.Module):
             step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
             # the reference keeps the raw conditional in the solver state (flow.py:779-796, 855-881)
             extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
-            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra)
+            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
@@ -102,7 +102,7 @@ class _FlowBase(nn.Module):
             raise NotImplementedError("gradients through the fused solve are not available; detach the input")
         method = _DEFAULT_SAMPLE_METHOD if method is None else method
         t_span = torch.tensor([1.0, 0.0], dtype=torch.float32)
-        if method == "dopri5":
+        if method in solvers.NATIVE_ADAPTIVE:
             x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional, raw_cond=raw_cond)
             return x * self.target_scale + self.target_shift
         x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional,

@@ -95,6 +95,7 @@ DOPRI5_FIXED = Tableau(
 
 FIXED_METHODS = {t.name: t for t in (EULER, MIDPOINT, HEUN3, RK4_38, RK4_CLASSIC, DOPRI5_FIXED)}
 ADAPTIVE_METHODS = ("dopri5", "dopri8", "bosh3", "fehlberg2", "adaptive_heun")
+NATIVE_ADAPTIVE = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")     # adaptive.TABLEAUX (dopri8: 13 stages > 7 slots)
 
 
 def resolve_method(method: str) -> Tableau:
@@ -102,9 +103,9 @@ def resolve_method(method: str) -> Tableau:
         return FIXED_METHODS[method]
     if method in ADAPTIVE_METHODS:
         raise NotImplementedError(
-            f"method={method!r} is an adaptive-step solver; the MI355X path integrates on a fixed grid. "
-            f"Pass one of {sorted(FIXED_METHODS)} with options={{'step_size': h}} "
-            "(e.g. method='rk4', options={'step_size': (1 - epsilon) / 100}).")
+            f"method={method!r}: of torchdiffeq's adaptive solvers {NATIVE_ADAPTIVE} run natively (one launch per attempted "
+            "step); dopri8 needs 13 stage slots and the fused kernels keep 7 on chip.  Fixed grids: "
+            f"{sorted(FIXED_METHODS)} with options={{'step_size': h}}.")
     raise ValueError(f"unknown ODE method {method!r}; supported: {sorted(FIXED_METHODS)}")
 
 

@@ -452,8 +452,20 @@ def _tuple_norm(parts):
     return max(p.abs().pow(2).mean().sqrt() for p in parts)
 
 
-def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
-    """Adaptive dopri5 from ``t[0]`` to ``t[-1]`` for a tuple state; returns the tuple at ``t[-1]``.
+# the other embedded pairs torchdiffeq offers with at most 7 stages (bosh3.py, fehlberg2.py, adaptive_heun.py):
+# name -> (order, alpha, beta, c_sol, c_error, c_mid)
+_ADAPTIVE_TABLEAUX = {
+    "bosh3": (3, [1 / 2, 3 / 4, 1.0], [[1 / 2], [0.0, 3 / 4], [2 / 9, 1 / 3, 4 / 9]], [2 / 9, 1 / 3, 4 / 9, 0.0],
+              [2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8], [0.0, 0.5, 0.0, 0.0]),
+    "fehlberg2": (2, [1 / 2, 1.0], [[1 / 2], [1 / 256, 255 / 256]], [1 / 512, 255 / 256, 1 / 512],
+                  [-1 / 512, 0.0, 1 / 512], [0.0, 0.5, 0.0]),
+    "adaptive_heun": (2, [1.0], [[1.0]], [0.5, 0.5], [0.5, -0.5], [0.5, 0.0]),
+}
+
+
+def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri5"):
+    """Adaptive dopri5 (or another embedded pair of `_ADAPTIVE_TABLEAUX`) from ``t[0]`` to ``t[-1]`` for a tuple state;
+    returns the tuple at ``t[-1]``.
 
     Follows torchdiffeq's RKAdaptiveStepsizeODESolver: float64 time, stages evaluated with the time
     cast to the state dtype, one step size for the whole batch chosen from the mixed RMS norm of
@@ -463,6 +475,10 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
     opts = dict(options or {})
     min_step = float(opts.get("min_step", 0.0))
     max_step = float(opts.get("max_step", float("inf")))
+    if method == "dopri5":
+        order, ALPHA, BETA, C_SOL, C_ERR, C_MID = 5, _DP5_ALPHA, _DP5_BETA, _DP5_C_SOL, _DP5_C_ERR, _DP5_C_MID
+    else:
+        order, ALPHA, BETA, C_SOL, C_ERR, C_MID = _ADAPTIVE_TABLEAUX[method]
     t = t.double()
     if bool(t[0] > t[-1]):
         t = -t
@@ -485,7 +501,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
     if d1 <= 1e-15 and d2 <= 1e-15:
         h1 = torch.max(torch.tensor(1e-6, dtype=dty), h0 * 1e-3)
     else:
-        h1 = (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+        h1 = (0.01 / max(d1, d2)) ** (1.0 / order)
     dt = torch.min(100 * h0, h1.abs()).double()
 
     y, f = tuple(y0), f0
@@ -498,13 +514,13 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
             raise AssertionError(f"underflow in dt {float(dt)}")  # torchdiffeq's assertion
         ta32, dt32, tb32 = ta.to(dty), dt.to(dty), tb.to(dty)
         ks = [f]
-        for alpha, beta in zip(_DP5_ALPHA, _DP5_BETA):
+        for alpha, beta in zip(ALPHA, BETA):
             ti = tb32 if alpha == 1.0 else ta32 + alpha * dt32
             yi = tuple(a + b for a, b in zip(y, comb(ks, beta, dt32)))
             ks.append(func(ti, yi))
-        y1 = tuple(a + b for a, b in zip(y, comb(ks, _DP5_C_SOL, dt32)))
+        y1 = tuple(a + b for a, b in zip(y, comb(ks, C_SOL, dt32)))
         f1 = ks[-1]
-        err = comb(ks, _DP5_C_ERR, dt32)
+        err = comb(ks, C_ERR, dt32)
         tol = tuple(atol + rtol * torch.max(a.abs(), b.abs()) for a, b in zip(y, y1))
         ratio = _tuple_norm([e / s for e, s in zip(err, tol)]).abs()
         accept = bool(ratio <= 1)
@@ -513,7 +529,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
         if dt <= min_step:
             accept = True
         if accept:
-            ymid = tuple(a + b for a, b in zip(y, comb(ks, _DP5_C_MID, dt32)))
+            ymid = tuple(a + b for a, b in zip(y, comb(ks, C_MID, dt32)))
             last = (ta, tb, dt32, y, y1, ymid, f, f1)
             t_lo, t_hi = ta, tb
             y, f = y1, f1
@@ -524,7 +540,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
             dt = dt * 10.0
         else:
             dfactor = 1.0 if ratio < 1 else 0.2
-            dt = dt * min(10.0, max(0.9 / float(ratio) ** 0.2, dfactor))
+            dt = dt * min(10.0, max(0.9 / float(ratio) ** (1.0 / order), dfactor))
         dt = dt.clamp(min_step, max_step)
     ta, tb, dt32, ya, yb, ymid, fa, fb = last
     x = ((t[-1] - ta) / (tb - ta)).to(dty)
@@ -545,8 +561,8 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None):
 
 def odeint(func, y0, t, method="rk4", options=None, rtol=1e-7, atol=1e-9):
     """Dispatch like torchdiffeq.odeint for the methods restated here."""
-    if method == "dopri5":
-        return odeint_dopri5(func, y0, t, rtol, atol, options)
+    if method == "dopri5" or method in _ADAPTIVE_TABLEAUX:
+        return odeint_dopri5(func, y0, t, rtol, atol, options, method)
     return odeint_fixed(func, y0, t, method, options)
 
 

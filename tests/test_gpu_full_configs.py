@@ -269,6 +269,26 @@ def test_replaced_layer_is_repacked():
     assert torch.equal(b, c)
 
 
+@pytest.mark.parametrize("method", ["bosh3", "fehlberg2", "adaptive_heun"])
+def test_other_adaptive_methods_run_natively(method):
+    """`method=` is passed through to torchdiffeq by the reference (diffusion.py:631-639): its other embedded pairs
+    with at most 7 stages run on the same one-launch-per-attempt driver; against the oracle's restatement."""
+    sm, so32, _ = _seeded_score_model(4, 0, [128, 128], "VESDE", False, 191)
+    torch.manual_seed(8)
+    base = torch.randn(200, 4)
+    x, _ = sm.sample_ode_from_base(base.to(DEV), method=method, atol=1e-5, rtol=1e-5)
+    assert sm.last_solver_stats["accepted"] >= 5
+    assert _state_err(x, so32.sample_ode_from_base(base, None, method, None, 1e-5, 1e-5)) < 5e-4
+    x0 = torch.randn(48, 4) * 0.5
+    sm.hutch = True
+    torch.manual_seed(5)
+    lp = sm.log_prob(x0.to(DEV), method=method, atol=1e-5, rtol=1e-5)
+    ref = so32.log_prob(x0, None, method, {"min_step": 1e-6}, "hutch", sm.e.cpu(), 1e-5, 1e-5)
+    assert _logp_err(lp, ref) < 5e-4
+    with pytest.raises(NotImplementedError, match="dopri8"):
+        sm.sample_ode_from_base(base.to(DEV), method="dopri8")
+
+
 # ---- bench.py's N > 1 branch ---------------------------------------------------------------------------------------
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """The driver launches bench.py for N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`.  No second

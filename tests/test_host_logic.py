@@ -357,6 +357,35 @@ def test_adaptive_dopri5_driver_matches_oracle(case, built_library):
         assert max_rel(lp[:, None], dlp, floor=1.0) < TOL
 
 
+@pytest.mark.parametrize("method", ["bosh3", "fehlberg2", "adaptive_heun"])
+def test_other_embedded_pairs_match_oracle(method, built_library):
+    """torchdiffeq's other adaptive solvers with at most 7 stages run on the same driver (one launch per attempted step,
+    different tableau).  Emulated kernel vs the oracle's independent restatement, tolerances well below the bar;
+    also: the pair converges to the dopri5 answer (a wrong coefficient would not)."""
+    from flowfusion_amd import adaptive
+    torch.manual_seed(5)
+    meta = dict(D=3, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=False)
+    sm = D.ScoreModel(D.MLP(3, 0, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+    so = score_oracle(meta, {k: v.detach().clone() for k, v in sm.state_dict().items()}, torch.float64)
+    net = sm._net()
+    B = 5
+    x = torch.randn(B, 3) * 0.5
+    e = torch.sign(torch.randn(B, 3))
+    eps = float(torch.tensor(float(sm.sde.epsilon), dtype=torch.float32))
+    sched = lambda tr: sm._schedule(tr, "ode")[:3]
+    rtol = atol = 1e-6 if method != "bosh3" else 1e-7
+    step = net.make_step(sched, 1.0, MODE_HUTCH, "cpu", probe=e, launcher=_cpu_launcher(net, MODE_HUTCH, None, e))
+    solver = adaptive.Dopri5(step, True, rtol, atol, {"min_step": 1e-9}, method=method)
+    y, lp = solver.integrate(eps, 1.0, x, torch.zeros(B))
+    xT, dlp = so.solve_odes_forward(x.double(), None, method, {"min_step": 1e-9}, "hutch", e.double(), atol, rtol)
+    assert solver.n_accepted >= 5
+    assert max_rel(y, xT, floor=xT.abs().max().item()) < 2e-4 and max_rel(lp[:, None], dlp, floor=1.0) < 2e-4
+    x5, d5 = so.solve_odes_forward(x.double(), None, "dopri5", {"min_step": 1e-9}, "hutch", e.double(), 1e-9, 1e-9)
+    assert max_rel(y, x5, floor=x5.abs().max().item()) < 1e-3 and max_rel(lp[:, None], d5, floor=1.0) < 1e-3
+    with pytest.raises(NotImplementedError, match="dopri8"):
+        adaptive.Dopri5(step, True, rtol, atol, None, method="dopri8")
+
+
 def test_adaptive_nan_error_estimate_raises_like_torchdiffeq(built_library):
     """VP schedules are undefined for t < 0; an overshooting last step makes the error estimate NaN,
     upon which torchdiffeq asserts ('underflow in dt nan').  The driver must not spin."""
