@@ -115,6 +115,75 @@ __device__ __forceinline__ void act_unit(const f32x16& acc, u32x4 (&bf)[2][3], b
     split2(act1<TANGENTS>(acc[2 * U], is_tangent), act1<TANGENTS>(acc[2 * U + 1], is_tangent), bf[U >> 2], U & 3);
 }
 
+// The same unit cut into four stages that are issued one GROUP (6 MFMAs, ~190 cycles) apart, so that no instruction
+// waits on a transcendental issued just before it: the wavefront issues in order, and a VALU instruction stalled on
+// its operand holds the next MFMA behind it.  Between stages a unit lives in four registers.
+struct UnitState {
+    float a0, a1, t0, t1;
+};
+template <bool TANGENTS, int U, int STAGE>
+__device__ __forceinline__ void act_unit_stage(const f32x16& acc, UnitState& u, u32x4 (&bf)[2][3], bool is_tangent)
+{
+    constexpr float NLOG2E = -1.44269504088896340736f;
+    if constexpr (STAGE == 0) {            // pre-activations out of the accumulator; exp(-a)
+        u.a0 = acc[2 * U];
+        u.a1 = acc[2 * U + 1];
+#ifdef FF_SPLIT_NOACT
+        u.t0 = u.a0; u.t1 = u.a1;
+#else
+        u.t0 = __builtin_amdgcn_exp2f(u.a0 * NLOG2E);
+        u.t1 = __builtin_amdgcn_exp2f(u.a1 * NLOG2E);
+#endif
+    } else if constexpr (STAGE == 1) {     // sigmoid
+#ifndef FF_SPLIT_NOACT
+        u.t0 = __builtin_amdgcn_rcpf(1.0f + u.t0);
+        u.t1 = __builtin_amdgcn_rcpf(1.0f + u.t1);
+#endif
+    } else if constexpr (STAGE == 2) {     // activation value (tangent columns: a' * SiLU'(a of the value column)); first residual
+#ifdef FF_SPLIT_NOACT
+        const float h0 = u.a0, h1 = u.a1;
+#else
+        float h0 = u.a0 * u.t0, h1 = u.a1 * u.t1;
+        if constexpr (TANGENTS) {
+            const float d0 = from_value_lane(__builtin_fmaf(h0, 1.0f - u.t0, u.t0));
+            const float d1 = from_value_lane(__builtin_fmaf(h1, 1.0f - u.t1, u.t1));
+            h0 = is_tangent ? u.a0 * d0 : h0;
+            h1 = is_tangent ? u.a1 * d1 : h1;
+        }
+#endif
+        u.a0 = h0;
+        u.a1 = h1;
+#ifndef FF_SPLIT_NOSPLIT        // timing experiment only: the three parts are all the top half (wrong results)
+        u.t0 = h0 - top(h0);
+        u.t1 = h1 - top(h1);
+#endif
+    } else {                               // second residual and the three packed words
+#ifdef FF_SPLIT_NOSPLIT
+        bf[U >> 2][0][U & 3] = bf[U >> 2][1][U & 3] = bf[U >> 2][2][U & 3] = pack_hi(u.a0, u.a1);
+#else
+        const float l0 = u.t0 - top(u.t0), l1 = u.t1 - top(u.t1);
+        bf[U >> 2][0][U & 3] = pack_hi(u.a0, u.a1);
+        bf[U >> 2][1][U & 3] = pack_hi(u.t0, u.t1);
+        bf[U >> 2][2][U & 3] = pack_hi(l0, l1);
+#endif
+    }
+}
+// Schedule of a tile's 8 units over the groups of a span: unit u starts at group `start(u)`, stage k runs at group
+// start(u) + k.  kind 0: a whole k-step pair of a hidden layer (16 groups: starts 0,1,3,4,6,7,9,10);
+// kind 1: the 14 groups after a tile's own completion (starts 2 + u);  kind 2: the 7 groups after layer 1's tile 0
+// (two units per group: starts 1 + u / 2).
+FF_HD constexpr int unit_start(int kind, int u) { return kind == 0 ? (3 * u) / 2 : (kind == 1 ? 2 + u : 1 + u / 2); }
+// run whatever stages of the tile's units fall on group `G` of the span
+template <bool TANGENTS, int KIND, int G>
+__device__ __forceinline__ void act_stages_at(const f32x16& acc, UnitState (&us)[8], u32x4 (&bf)[2][3], bool is_tangent)
+{
+    sfor<8>([&](auto uu) {
+        constexpr int U = decltype(uu)::value;
+        constexpr int k = G - unit_start(KIND, U);
+        if constexpr (k >= 0 && k < 4) act_unit_stage<TANGENTS, U, k>(acc, us[U], bf, is_tangent);
+    });
+}
+
 // LDS-DMA of one fragment: 64 lanes x 16 bytes from `g` (wave-uniform) + lane * 16 to LDS byte `lds_byte` + lane * 16.
 // Inline asm on purpose: as a builtin the DMA makes hipcc spill, and every spill reload then queues behind it.
 __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, int lane16)
@@ -196,6 +265,11 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
         for (int j4 = 0; j4 < 2; ++j4) ks[(s * 2 + j4) * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the state x lives in LDS as well (slot kSlots + 1; slot kSlots parks the stage input y): it is touched twice per
+    // evaluation, and 8 more live registers would spill inside the loop
+#pragma unroll
+    for (int j4 = 0; j4 < 2; ++j4)
+        ks[((kSlots + 1) * 2 + j4) * 256] = f32x4{x[4 * j4], x[4 * j4 + 1], x[4 * j4 + 2], x[4 * j4 + 3]};
     for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
         const float* bsrc = args.wpack + (size_t)stream_words(NT, K1S, NH);
@@ -286,8 +360,13 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
             for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(lds + wa_next + p * 1024);
         } else {
+#ifndef FF_SPLIT_NOWREAD        // timing experiment only: one group's fragments serve the whole granule (wrong results)
 #pragma unroll
             for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(lds + wa + ((GQ + 1) * 3 + p) * 1024);
+#else
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wn[p] = w[p];
+#endif
         }
     };
     auto post = [&](auto gq) __attribute__((always_inline)) {
@@ -300,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     };
 
     u32x4 bf[2][2][3];                                 // B fragments of the k-step pair in use / in preparation
+    UnitState us[8];                                   // activation units in flight (four stages, one group apart)
 
     // A hidden -> hidden layer (reads P, writes C) or, with OUT, the output layer (reads P, writes O[0]).
     // `refill` = LDS byte address of the bias vector the tiles of P are refilled with once consumed (their next use).
@@ -317,20 +397,15 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                     pre(std::integral_constant<int, q % 8>{});
                     if constexpr (OUT) group6(O, w, bf[p & 1][s]);
                     else group6(Cc[t], w, bf[p & 1][s]);
-                    // activation units in the shadow of the MFMAs just issued
+                    // activation stages in the shadow of the MFMAs just issued
                     if constexpr (OUT) {
-                        if constexpr (p < NT - 1) {    // four units per group
+                        if constexpr (p < NT - 1) {    // four whole units per group (the output layer is VALU-bound anyway)
                             sfor<4>([&](auto uu) { act_unit<TANGENTS, 4 * s + decltype(uu)::value>(P[p + 1], bf[(p + 1) & 1], is_tangent); });
                         }
-                    } else if constexpr (s == 1) {
-                        if constexpr (p < NT - 1) {
-                            act_unit<TANGENTS, t>(P[p + 1], bf[(p + 1) & 1], is_tangent);
-                        } else if constexpr (t == 1) { // last pair: the first tile of THIS layer's output, complete now
-                            act_unit<TANGENTS, 0>(Cc[0], bf[0], is_tangent);
-                            act_unit<TANGENTS, 1>(Cc[0], bf[0], is_tangent);
-                        } else if constexpr (t >= 2) {
-                            act_unit<TANGENTS, t>(Cc[0], bf[0], is_tangent);
-                        }
+                    } else if constexpr (p < NT - 1) {
+                        act_stages_at<TANGENTS, 0, 2 * t + s>(P[p + 1], us, bf[(p + 1) & 1], is_tangent);
+                    } else {                           // last pair: the first tile of THIS layer's output, complete after group 1
+                        act_stages_at<TANGENTS, 1, 2 * t + s>(Cc[0], us, bf[0], is_tangent);
                     }
                     post(std::integral_constant<int, q % 8>{});
                 });
@@ -349,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         float y[R];
 #pragma unroll
         for (int j4 = 0; j4 < 2; ++j4) {
-            f32x4 v = f32x4{x[4 * j4], x[4 * j4 + 1], x[4 * j4 + 2], x[4 * j4 + 3]};
+            f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) v += hdr->cin[s] * ks[(s * 2 + j4) * 256];
 #pragma unroll
@@ -373,13 +448,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 if constexpr (q == 0) fetch_c1(e + 1);                 // (after the weight DMAs of this granule)
 #endif
                 group6(A[t], w, yf[s]);
-                if constexpr (s == K1S - 1) {                           // tile 0 is complete: its activation rides here
-                    if constexpr (t == 1) {
-                        act_unit<TANGENTS, 0>(A[0], bf[0], is_tangent);
-                        act_unit<TANGENTS, 1>(A[0], bf[0], is_tangent);
-                    } else if constexpr (t >= 2) {
-                        act_unit<TANGENTS, t>(A[0], bf[0], is_tangent);
-                    }
+                if constexpr (s == K1S - 1) {                           // tile 0 is complete after group 0: its activation rides here
+                    act_stages_at<TANGENTS, 2, t>(A[0], us, bf[0], is_tangent);
                 }
                 post(std::integral_constant<int, q % 8>{});
             });
@@ -414,7 +484,11 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         if constexpr (TANGENTS) {
             float dot = 0.f;
 #pragma unroll
-            for (int r = 0; r < R; ++r) dot = __builtin_fmaf(x[r], O[r], dot);
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const f32x4 xv = ks[((kSlots + 1) * 2 + j4) * 256];          // tangent lanes: the probe e
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dot = __builtin_fmaf(xv[i], O[4 * j4 + i], dot);
+            }
             div = is_tangent ? __builtin_fmaf(a_e, ee, b_e * dot) : 0.f;
         }
 #pragma unroll
@@ -436,11 +510,10 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         if (flags & 1u) {
 #pragma unroll
             for (int j4 = 0; j4 < 2; ++j4) {
-                f32x4 v = f32x4{x[4 * j4], x[4 * j4 + 1], x[4 * j4 + 2], x[4 * j4 + 3]};
+                f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
 #pragma unroll
                 for (int s = 0; s < kSlots; ++s) v += hdr->cout[s] * ks[(s * 2 + j4) * 256];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[4 * j4 + i] = v[i];
+                ks[((kSlots + 1) * 2 + j4) * 256] = v;
             }
             if constexpr (TANGENTS) {
 #pragma unroll
@@ -463,13 +536,20 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         if (writer && hf == 0 && args.dlogp_out) args.dlogp_out[sample] = (args.dlogp_in ? args.dlogp_in[sample] : 0.f) + tot;
     }
     bool bad = false;
+    float xfin[R];
+#pragma unroll
+    for (int j4 = 0; j4 < 2; ++j4) {
+        const f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xfin[4 * j4 + i] = v[i];
+    }
     if (writer) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int d = kidx(0, hf, r);
             if (d < D) {
 #pragma clang fp contract(off)      // x * scale + shift as two roundings, like the reference's torch expression
-                float v = x[r];
+                float v = xfin[r];
                 bad |= (v != v);
                 if (args.out_scale) v = v * args.out_scale[d];
                 if (args.out_shift) v = v + args.out_shift[d];

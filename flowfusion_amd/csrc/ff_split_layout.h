@@ -50,7 +50,7 @@ FF_HD constexpr size_t total_words(int nt, int k1s, int n_hidden)
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
     int wbuf;    // kBuffers x 24 KiB weight granules
-    int slots;   // Runge-Kutta stage slots + the parked stage input: (kSlots + 1) x 2 x 256 threads x 16 B
+    int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (kSlots + 2) x 2 x 256 threads x 16 B
     int c1;      // 2 x H floats: first-layer bias of the current / next evaluation
     int hbias;   // (NH-1) x H floats + 32: hidden->hidden and output biases
     int zero;    // H floats of zeros (what tangent columns read instead of a bias)
@@ -61,7 +61,7 @@ FF_HD constexpr LdsMap lds_map(int H, int n_hidden)
     LdsMap m{};
     m.wbuf = 0;
     m.slots = kBuffers * kGranuleBytes;
-    m.c1 = m.slots + (7 + 1) * 2 * 256 * 16;
+    m.c1 = m.slots + (7 + 2) * 2 * 256 * 16;
     m.hbias = m.c1 + 2 * H * 4;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
     m.zero = m.hbias + nh1 * H * 4 + H * 4;      // (one spare vector: a tile read of the 32-float output bias stays inside)
