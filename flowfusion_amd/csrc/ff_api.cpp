@@ -93,9 +93,6 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
     if (precision == FF_PREC_BF16X3) return plan_split(dim, cond_dim, n_hidden, hidden_widths, mode, activation, plan);
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
-    // FF_ANY_ACT=1 sends SiLU networks to the run-time-activation kernels as well (A/B tests)
-    const char* force_any = getenv("FF_ANY_ACT");
-    const int need_any = (activation != FF_ACT_SILU || (force_any && atoi(force_any))) ? 1 : 0;
     if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     int wmax = 0;
     for (int i = 0; i < n_hidden; ++i) {
@@ -113,7 +110,7 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
         const ff::KernelEntry& k = ff::g_kernels[i];
         const int need_d = ff::regs_for(k.tile, dim);
         const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
-        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t || k.any_act != need_any) continue;
+        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t || k.act != activation) continue;
         if (pin_tile && k.tile != pin_tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
@@ -152,7 +149,7 @@ static bool plan_ok(const ff_mlp_plan_t* p)
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
     const int per_reg = 64 / k.tile;
     return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
-           p->activation >= 0 && p->activation < FF_ACT_COUNT && (p->activation == FF_ACT_SILU || k.any_act) &&
+           p->activation >= 0 && p->activation < FF_ACT_COUNT && p->activation == k.act &&
            p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
 }
 
@@ -406,7 +403,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.rng_seed = a->rng_seed; ka.rng_sample_offset = a->rng_sample_offset; ka.rng_noise_base = a->rng_noise_base;
     if (a->jac_out && a->mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     ka.jac_out = a->jac_out;
-    ka.act_kind = plan->activation; ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
+    ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;

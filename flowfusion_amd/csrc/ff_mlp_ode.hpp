@@ -141,122 +141,121 @@ struct ActGroup {
     float pre[4], t[4], r[4], h[4];
     int dv[4];
 };
-// Activation selected at run time (instantiations with GENERIC_ACT; include/flowfusion_amd.h FF_ACT_*).
+// Parameters of the activation (FF_ACT_LEAKY_RELU: p0 = negative slope; FF_ACT_ELU: p0 = alpha; FF_ACT_SOFTPLUS:
+// p0 = beta, p1 = threshold; include/flowfusion_amd.h).  Wave-uniform.
 struct ActSpec {
-    int kind;
     float p0, p1;
+    float ip0;      // 1 / p0 (softplus divides by beta: one division per kernel instead of one per element)
 };
-// value h = act(a) and slope d = act'(a) of 4 pre-activations.  `kind` is wave-uniform (an SGPR), so
-// the switch is a scalar branch around straight-line code.
-__device__ __forceinline__ void act_generic(const ActSpec& s, const float (&a)[4], float (&h)[4], float (&d)[4])
+
+// Activations other than SiLU (template parameter ACT = FF_ACT_* code, compiled in): value h = act(a) and slope
+// d = act'(a) of 4 pre-activations, cut into the same five stages as the SiLU path -- argument, exponential,
+// reciprocal / logarithm, value and slope, select -- so that no instruction waits on a transcendental issued just
+// before it.  Formulas follow torch.nn's definitions; exp / log / rcp are the hardware approximations (1 ulp), erf of
+// GELU is Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7).
+template <bool TANGENTS, int ACT, int STAGE>
+__device__ __forceinline__ void act_stage_kind(ActGroup& g, float* __restrict__ dst, bool is_tangent,
+                                               int value_lane_bytes, const ActSpec& s)
 {
     constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
-    switch (s.kind) {
-    default:   // FF_ACT_SILU
+    constexpr float SQ2PI = 0.79788456080286535588f;
+    float d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * -LOG2E));
-            h[i] = a[i] * r;
-            d[i] = __builtin_fmaf(h[i], 1.0f - r, r);
+    for (int i = 0; i < 4; ++i) {
+        const float a = g.pre[i];
+        d[i] = 0.f;
+        if constexpr (ACT == 1) {                      // tanh(a) = 2 sigmoid(2a) - 1
+            if constexpr (STAGE == 0) g.t[i] = a * (-2.0f * LOG2E);
+            else if constexpr (STAGE == 1) g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);
+            else if constexpr (STAGE == 2) g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
+            else if constexpr (STAGE == 3) {
+                g.h[i] = __builtin_fmaf(2.0f, g.r[i], -1.0f);
+                d[i] = __builtin_fmaf(-g.h[i], g.h[i], 1.0f);
+            }
+        } else if constexpr (ACT == 2) {               // sigmoid
+            if constexpr (STAGE == 0) g.t[i] = a * -LOG2E;
+            else if constexpr (STAGE == 1) g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);
+            else if constexpr (STAGE == 2) g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
+            else if constexpr (STAGE == 3) {
+                g.h[i] = g.r[i];
+                d[i] = g.r[i] * (1.0f - g.r[i]);
+            }
+        } else if constexpr (ACT == 3) {               // relu
+            if constexpr (STAGE == 3) {
+                g.h[i] = a > 0.f ? a : 0.f;
+                d[i] = a > 0.f ? 1.f : 0.f;
+            }
+        } else if constexpr (ACT == 4) {               // leaky relu
+            if constexpr (STAGE == 3) {
+                g.h[i] = a > 0.f ? a : a * s.p0;
+                d[i] = a > 0.f ? 1.f : s.p0;
+            }
+        } else if constexpr (ACT == 5) {               // elu
+            if constexpr (STAGE == 0) g.t[i] = fminf(a, 0.f) * LOG2E;
+            else if constexpr (STAGE == 1) g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);
+            else if constexpr (STAGE == 3) {
+                g.h[i] = a > 0.f ? a : s.p0 * (g.t[i] - 1.0f);
+                d[i] = a > 0.f ? 1.f : s.p0 * g.t[i];
+            }
+        } else if constexpr (ACT == 6) {               // softplus: log(1 + exp(beta a)) / beta, linear above the threshold
+            if constexpr (STAGE == 0) g.t[i] = -fabsf(a * s.p0) * LOG2E;
+            else if constexpr (STAGE == 1) g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);            // e = exp(-|z|)
+            else if constexpr (STAGE == 2) {
+                g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
+                g.h[i] = __builtin_amdgcn_logf(1.0f + g.t[i]);                                  // log2(1 + e)
+            } else if constexpr (STAGE == 3) {
+                const float z = a * s.p0;
+                const float sp = __builtin_fmaf(g.h[i], LN2, fmaxf(z, 0.f));
+                const bool lin = z > s.p1;
+                g.h[i] = lin ? a : sp * s.ip0;
+                d[i] = lin ? 1.f : (z >= 0.f ? g.r[i] : g.t[i] * g.r[i]);
+            }
+        } else if constexpr (ACT == 7) {               // gelu (erf form): a Phi(a)
+            if constexpr (STAGE == 0) {
+                const float u = fabsf(a) * 0.70710678118654752440f;
+                g.t[i] = -u * u * LOG2E;
+                g.r[i] = __builtin_fmaf(0.3275911f, u, 1.0f);
+            } else if constexpr (STAGE == 1) {
+                g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);                                        // exp(-a^2 / 2)
+                g.r[i] = __builtin_amdgcn_rcpf(g.r[i]);
+            } else if constexpr (STAGE == 2) {
+                const float t = g.r[i];
+                float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+                poly = __builtin_fmaf(poly, t, 1.421413741f);
+                poly = __builtin_fmaf(poly, t, -0.284496736f);
+                poly = __builtin_fmaf(poly, t, 0.254829592f);
+                g.h[i] = poly * t * g.t[i];                                                      // 1 - erf(u), u >= 0
+            } else if constexpr (STAGE == 3) {
+                const float phi = a >= 0.f ? 1.0f - 0.5f * g.h[i] : 0.5f * g.h[i];               // Phi(a)
+                g.h[i] = a * phi;
+                d[i] = __builtin_fmaf(a * 0.39894228040143267794f, g.t[i], phi);
+            }
+        } else {                                       // gelu, tanh form: a sigmoid(2 w), w = sqrt(2/pi) (a + 0.044715 a^3)
+            static_assert(ACT == 8, "unknown activation code");
+            if constexpr (STAGE == 0) g.t[i] = SQ2PI * a * __builtin_fmaf(0.044715f, a * a, 1.0f) * (-2.0f * LOG2E);
+            else if constexpr (STAGE == 1) g.t[i] = __builtin_amdgcn_exp2f(g.t[i]);
+            else if constexpr (STAGE == 2) g.r[i] = __builtin_amdgcn_rcpf(1.0f + g.t[i]);
+            else if constexpr (STAGE == 3) {
+                const float dw = SQ2PI * __builtin_fmaf(3.0f * 0.044715f, a * a, 1.0f);
+                g.h[i] = a * g.r[i];
+                d[i] = __builtin_fmaf(2.0f * dw * g.h[i], 1.0f - g.r[i], g.r[i]);
+            }
         }
-        break;
-    case 1:    // tanh(a) = 2 sigmoid(2a) - 1
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * (-2.0f * LOG2E)));
-            h[i] = __builtin_fmaf(2.0f, r, -1.0f);
-            d[i] = __builtin_fmaf(-h[i], h[i], 1.0f);
+        // common tail: the tangent columns take the slope of their value column
+        if constexpr (STAGE == 3) {
+            if constexpr (TANGENTS) g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d[i]));
+            else dst[i] = g.h[i];
+        } else if constexpr (STAGE == 4 && TANGENTS) {
+            dst[i] = is_tangent ? __builtin_bit_cast(float, g.dv[i]) * a : g.h[i];
         }
-        break;
-    case 2:    // sigmoid
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[i] * -LOG2E));
-            h[i] = r;
-            d[i] = r * (1.0f - r);
-        }
-        break;
-    case 3:    // relu
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h[i] = a[i] > 0.f ? a[i] : 0.f;
-            d[i] = a[i] > 0.f ? 1.f : 0.f;
-        }
-        break;
-    case 4:    // leaky relu, p0 = negative slope
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h[i] = a[i] > 0.f ? a[i] : a[i] * s.p0;
-            d[i] = a[i] > 0.f ? 1.f : s.p0;
-        }
-        break;
-    case 5:    // elu, p0 = alpha
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float e = __builtin_amdgcn_exp2f(fminf(a[i], 0.f) * LOG2E);
-            h[i] = a[i] > 0.f ? a[i] : s.p0 * (e - 1.0f);
-            d[i] = a[i] > 0.f ? 1.f : s.p0 * e;
-        }
-        break;
-    case 6:    // softplus, p0 = beta, p1 = threshold:  log(1 + exp(beta a)) / beta, linear above the threshold
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float z = a[i] * s.p0;
-            const float e = __builtin_amdgcn_exp2f(-fabsf(z) * LOG2E);
-            const float r = __builtin_amdgcn_rcpf(1.0f + e);
-            const float sp = __builtin_fmaf(__builtin_amdgcn_logf(1.0f + e), LN2, fmaxf(z, 0.f));
-            const bool lin = z > s.p1;
-            h[i] = lin ? a[i] : sp / s.p0;
-            d[i] = lin ? 1.f : (z >= 0.f ? r : e * r);
-        }
-        break;
-    case 7:    // gelu (erf form): a Phi(a); erf by Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float u = fabsf(a[i]) * 0.70710678118654752440f;
-            const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, u, 1.0f));
-            const float g = __builtin_amdgcn_exp2f(-u * u * LOG2E);                    // exp(-a^2/2)
-            float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-            poly = __builtin_fmaf(poly, t, 1.421413741f);
-            poly = __builtin_fmaf(poly, t, -0.284496736f);
-            poly = __builtin_fmaf(poly, t, 0.254829592f);
-            const float erfc_u = poly * t * g;                                         // 1 - erf(u), u >= 0
-            const float phi = a[i] >= 0.f ? 1.0f - 0.5f * erfc_u : 0.5f * erfc_u;      // Phi(a)
-            h[i] = a[i] * phi;
-            d[i] = __builtin_fmaf(a[i] * 0.39894228040143267794f, g, phi);
-        }
-        break;
-    case 8:    // gelu, tanh form: a sigmoid(2 w), w = sqrt(2/pi) (a + 0.044715 a^3)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float a2 = a[i] * a[i];
-            const float w = 0.79788456080286535588f * a[i] * __builtin_fmaf(0.044715f, a2, 1.0f);
-            const float dw = 0.79788456080286535588f * __builtin_fmaf(3.0f * 0.044715f, a2, 1.0f);
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w * (-2.0f * LOG2E)));
-            h[i] = a[i] * r;
-            d[i] = __builtin_fmaf(2.0f * dw * h[i], 1.0f - r, r);
-        }
-        break;
     }
 }
-template <bool TANGENTS, bool GENERIC_ACT, int STAGE>
+template <bool TANGENTS, int ACT, int STAGE>
 __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, bool is_tangent,
                                           int value_lane_bytes, const ActSpec& spec)
 {
-    if constexpr (GENERIC_ACT) {
-        // run-time activation: not latency-tuned -- value and slope are computed in one piece in stage 3
-        // (short live ranges), the cross-lane fetch of the slope follows at once and is consumed in stage 4
-        if constexpr (STAGE == 3) {
-            act_generic(spec, g.pre, g.h, g.r);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (TANGENTS) g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, g.r[i]));
-                else dst[i] = g.h[i];
-            }
-        } else if constexpr (STAGE == 4 && TANGENTS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = is_tangent ? __builtin_bit_cast(float, g.dv[i]) * g.pre[i] : g.h[i];
-        }
+    if constexpr (ACT != 0) {
+        act_stage_kind<TANGENTS, ACT, STAGE>(g, dst, is_tangent, value_lane_bytes, spec);
         return;
     }
 #ifdef FF_DEBUG_LINEAR_ACT      // timing experiment only: identity activation (wrong results)
@@ -414,7 +413,7 @@ FF_HD constexpr int act_group_at(const LayerGeom& L, int phys, int gpb, int M, i
 // to give every SIMD a tile of its own.  Same packed weights, same fp32 FMA chains in the same order (results equal the
 // one-wavefront kernel's bit for bit); state, stage slots and bookkeeping are replicated in the four wavefronts and
 // wavefront 0 writes the outputs.  The launcher picks the twin by batch size (ff_api.cpp).
-template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, bool GENERIC_ACT = false, bool COOP = false>
+template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, int ACT = 0, bool COOP = false>
 __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args)
 {
     static_assert(kChunkPad % RING == 0, "ring must divide the chunk padding");
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wavefront of the workgroup
     const int D = args.dim;
     const int C = args.cond_dim;
-    const ActSpec aspec = {args.act_kind, args.act_p0, args.act_p1};
+    const ActSpec aspec = {args.act_p0, args.act_p1, ACT == 6 ? 1.0f / args.act_p0 : 0.f};
 
     // ---- column roles -----------------------------------------------------------------
     long long sample;
@@ -668,7 +667,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ag.pre[i] = acc[j].reg(4 * r4 + i);
                         static_for<kActStages>([&](auto kk) {
-                            act_stage<TANGENTS, GENERIC_ACT, decltype(kk)::value>(ag, out, is_tangent, value_lane_bytes, aspec);
+                            act_stage<TANGENTS, ACT, decltype(kk)::value>(ag, out, is_tangent, value_lane_bytes, aspec);
                         });
                         xb[((ob0 + j) * RBQ + r4) * 64] = f32x4{out[0], out[1], out[2], out[3]};
                     });
@@ -750,7 +749,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ag[gi].pre[i] = pend[4 * gi + i];
                     }
-                    act_stage<TANGENTS, GENERIC_ACT, k>(ag[gi], &P[(NB - 1) * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
+                    act_stage<TANGENTS, ACT, k>(ag[gi], &P[(NB - 1) * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
                 }
             });
         };
@@ -768,7 +767,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                         for (int i = 0; i < 4; ++i)
                             ag[4 + id % 8].pre[i] = acc[blk].reg(4 * gi + i);
                     }
-                    act_stage<TANGENTS, GENERIC_ACT, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
+                    act_stage<TANGENTS, ACT, k>(ag[4 + id % 8], &P[blk * RB + 4 * gi], is_tangent, value_lane_bytes, aspec);
                 }
             });
         };

@@ -15,7 +15,7 @@ struct KernelEntry {
     int dregs;      // state registers  (covers dim <= dregs * 64/tile)
     int cregs;      // conditional registers
     int tangents;   // 1: divergence-capable instantiation
-    int any_act;    // 0: SiLU compiled in; 1: activation selected at run time (FF_ACT_*)
+    int act;        // FF_ACT_* code of the hidden activation this instantiation has compiled in (0 = SiLU)
     LaunchFn launch;
     const char* name;
     LaunchFn launch_coop;   // cooperative twin for small batches (one tile per workgroup, ff_mlp_ode.hpp COOP) or NULL

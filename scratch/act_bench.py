@@ -19,6 +19,6 @@ for act in (torch.nn.SiLU(), torch.nn.Tanh(), torch.nn.GELU(), torch.nn.Softplus
             s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); net.integrate(x, tab, mode, probe=e); t.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(t))
         ms = min(ts)
-        k = _native.lib().ff_kernel_name(net.plan(mode).kernel_id).decode()
+        k = _native.kernel_name(net.plan(mode))
         flop = 2 * 206848 * 400 * B * (1, 2)[mode]
         print(f"{type(act).__name__:9s} mode {mode} {k:36s} {ms:8.2f} ms {B/ms*1e3:10.0f} samples/s {flop/ms/1e9:7.2f} TFLOP/s", flush=True)

@@ -622,26 +622,6 @@ def test_activations_against_oracle(act):
         assert _logp_err(lp, fo64.log_prob(x.double(), None, "rk4", opts).float()) < LOGP_TOL, act
 
 
-def test_silu_on_the_runtime_activation_kernels(monkeypatch):
-    """FF_ANY_ACT=1 routes SiLU networks to the run-time-activation kernels: same results as the SiLU
-    kernels (the two evaluate the same expression)."""
-    from flowfusion_amd import _native
-    outs = []
-    for force in ("0", "1"):
-        monkeypatch.setenv("FF_ANY_ACT", force)
-        sm, _, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 3)
-        name = _native.lib().ff_kernel_name(sm._net().plan(2).kernel_id)
-        assert (b"_act" in name) == (force == "1")
-        torch.manual_seed(8)
-        x = torch.randn(300, 16)
-        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
-        x0, _ = sm.sample_ode_from_base(x.to(DEV), method="rk4", options=opts)
-        lp = sm.log_prob(x[:64].to(DEV), method="rk4", options=opts)
-        outs.append((x0.cpu(), lp.cpu()))
-    assert _state_err(outs[1][0], outs[0][0]) < 1e-6
-    assert _logp_err(outs[1][1], outs[0][1]) < 1e-6
-
-
 # ---- in-kernel (counter-based) noise for Euler-Maruyama --------------------------------------------------------
 @pytest.mark.parametrize("D,C,units", [(6, 2, [64, 64]), (32, 8, [256] * 4), (40, 0, [512, 512])])
 def test_philox_noise_matches_restatement_and_is_shard_invariant(D, C, units):

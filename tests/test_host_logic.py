@@ -281,7 +281,9 @@ def test_activation_plumbing_matches_oracle(act, built_library):
     sm = D.ScoreModel(D.MLP(5, 2, 8, [48, 64], activation=act), D.VESDE(), no_sigma=False).eval()
     net = sm._net()
     plan = _native.plan_words(net.plan(MODE_EXACT))
-    assert plan[8] == net.act[0] != _native.ACT_SILU and b"_act" in built_library.ff_kernel_name(plan[6])
+    # a kernel with THIS activation compiled in (name suffix _a<FF_ACT code>)
+    assert plan[8] == net.act[0] != _native.ACT_SILU
+    assert built_library.ff_kernel_name(plan[6]).endswith(b"_a%d" % net.act[0])
     so = O.ScoreOracle(O.mlp_params_from_state_dict(sm.state_dict()), O.VE(dtype=torch.float64), no_sigma=False,
                        dtype=torch.float64, activation=act)
     x0, cond = torch.randn(7, 5), torch.randn(7, 2)
