@@ -94,6 +94,17 @@ class CombineArgs(ctypes.Structure):      # ff_combine_args
     ]
 
 
+class NormTerm(ctypes.Structure):         # ff_norm_term
+    _fields_ = [
+        ("num", ctypes.c_void_p),
+        ("sub", ctypes.c_void_p),
+        ("scale0", ctypes.c_void_p),
+        ("scale1", ctypes.c_void_p),
+        ("n", ctypes.c_int64),
+    ]
+
+
+NORM_TERMS = 3                      # FF_NORM_TERMS
 PRIOR_NOISE_INDEX = 0xFFFFFFFF     # FF_PRIOR_NOISE_INDEX
 
 _lib = None
@@ -145,6 +156,10 @@ def lib() -> ctypes.CDLL:
     L.ff_normal_fill.restype = ctypes.c_int
     L.ff_normal_fill.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64,
                                  ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p]
+    L.ff_scaled_rms_workspace_bytes.restype = ctypes.c_size_t
+    L.ff_scaled_rms.restype = ctypes.c_int
+    L.ff_scaled_rms.argtypes = [ctypes.POINTER(NormTerm), ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.ff_stage_combine.restype = ctypes.c_int
     L.ff_stage_combine.argtypes = [ctypes.POINTER(CombineArgs), ctypes.c_void_p]
     _lib = L
@@ -257,6 +272,43 @@ def stage_combine(out: torch.Tensor, x: Optional[torch.Tensor], ks, coefs, x_coe
     if rc != FF_OK:
         raise _err(rc, "ff_stage_combine")
     return out
+
+
+_norm_ws = {}     # (device index, stream) -> (workspace, out) of ff_scaled_rms
+
+
+def scaled_rms(terms, atol: float, rtol: float, check: Optional[torch.Tensor] = None) -> List[float]:
+    """ff_scaled_rms: ``terms`` = up to 3 tuples (num, sub or None, scale0, scale1 or None) of equal-sized fp32 device
+    tensors; returns [rms_0, .., rms_{n-1}, nonfinite(check)] as Python floats -- one launch, one read-back (this is
+    the single host synchronisation of an attempted adaptive step)."""
+    dev = terms[0][0].device
+    if dev.type != "cuda":
+        raise RuntimeError("flowfusion_amd: ff_scaled_rms works on device memory (there is no CPU path)")
+    if not 1 <= len(terms) <= NORM_TERMS:
+        raise RuntimeError(f"scaled_rms: 1..{NORM_TERMS} terms")
+    arr = (NormTerm * NORM_TERMS)()
+    keep = []
+    for i, (num, sub, s0, s1) in enumerate(terms):
+        for t in (num, sub, s0, s1):
+            if t is not None and t.numel() != num.numel():
+                raise RuntimeError("scaled_rms: the arrays of a term differ in size")
+        arr[i].num, arr[i].sub = _chk(num, "num", dev), _chk(sub, "sub", dev)
+        arr[i].scale0, arr[i].scale1 = _chk(s0, "scale0", dev), _chk(s1, "scale1", dev)
+        arr[i].n = num.numel()
+        keep.append((num, sub, s0, s1))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (dev.index, stream)
+        if key not in _norm_ws:
+            nbytes = int(lib().ff_scaled_rms_workspace_bytes())
+            _norm_ws[key] = (torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev),
+                             torch.empty(NORM_TERMS + 1, dtype=torch.float32, device=dev))
+        ws, out = _norm_ws[key]
+        rc = lib().ff_scaled_rms(arr, len(terms), float(atol), float(rtol), _chk(check, "check", dev),
+                                 0 if check is None else check.numel(), out.data_ptr(), ws.data_ptr(), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_scaled_rms")
+    return out[: len(terms) + 1].tolist()
 
 
 _PLAN_WORDS = ctypes.sizeof(PlanStruct) // 4

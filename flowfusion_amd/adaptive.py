@@ -156,7 +156,44 @@ class Dopri5:
         return aux, None
 
     # -- torchdiffeq's helpers, state in fp32 on the device, time in float64 on the host ----------
+    def _norms(self, terms, check=None):
+        """Mixed norm (max over the components of their scaled RMS norms) of `terms` = [(num, sub, scale0, scale1), ..],
+        and whether `check` holds a non-finite value.  On the GPU: one ff_scaled_rms launch and one read-back, the
+        only host synchronisation of an attempted step.  (CPU tensors -- the kernel-semantics emulator of the tests --
+        take the same arithmetic in torch ops.)"""
+        if terms[0][0].is_cuda:
+            from . import _native
+            out = []
+            for i in range(0, len(terms), _native.NORM_TERMS):
+                part = terms[i:i + _native.NORM_TERMS]
+                vals = _native.scaled_rms([tuple(None if t is None else t.reshape(-1) for t in term) for term in part],
+                                          self.atol, self.rtol, check.reshape(-1) if (check is not None and i == 0) else None)
+                out.extend(vals[:len(part)])
+                if i == 0:
+                    bad = vals[len(part)] != 0.0
+            return max(out), (bad if check is not None else False)
+        parts = []
+        for num, sub, s0, s1 in terms:
+            sc = s0.abs() if s1 is None else torch.max(s0.abs(), s1.abs())
+            parts.append((num if sub is None else num - sub) / (self.atol + self.rtol * sc))
+        return _mixed_norm(parts), (not bool(torch.isfinite(check).all()) if check is not None else False)
+
     def _select_initial_step(self, t0, y, lp, f0, fl0):
+        if y.is_cuda:
+            ys = [p for p in (y, lp) if p is not None]
+            fs = [p for p in (f0, fl0) if p is not None]
+            d0, _ = self._norms([(a, None, a, None) for a in ys] + [(c, None, c, None) for c in self.norm_only])
+            d1, _ = self._norms([(f, None, a, None) for f, a in zip(fs, ys)])
+            h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+            h0 = float(_f32(abs(h0)))
+            f1, fl1 = self._deriv(float(_f32(t0)) + h0, y, lp, k1=f0, kl1=fl0, h=h0)
+            f1s = [p for p in (f1, fl1) if p is not None]
+            d2 = abs(self._norms([(a, b, c, None) for a, b, c in zip(f1s, fs, ys)])[0] / h0)
+            if d1 <= 1e-15 and d2 <= 1e-15:
+                h1 = max(1e-6, h0 * 1e-3)
+            else:
+                h1 = (0.01 / max(d1, d2)) ** (1.0 / float(self.tab.order))
+            return min(100 * h0, abs(h1))
         scale = [self.atol + p.abs() * self.rtol for p in (y, lp) if p is not None]
         ys = [p for p in (y, lp) if p is not None]
         fs = [p for p in (f0, fl0) if p is not None]
@@ -210,18 +247,20 @@ class Dopri5:
             aux, aux_lp = self._attempt(ta, dt, tb, y, lp, f0, fl0)
             self.n_attempts += 1
             y1, f1, ymid, yerr = aux[0], aux[1], aux[2], aux[3]
+            # error ratio (mixed norm of err / (atol + rtol max(|y0|, |y1|))) and the finiteness of the new state: one
+            # reduction launch and one read-back on the GPU
+            terms = [(yerr, None, y, y1)]
             if self.has_lp:
                 lp1, fl1, lpmid, lperr = aux_lp[0], aux_lp[1], aux_lp[2], aux_lp[3]
-                ratio = self._error_ratio([yerr, lperr], [y, lp], [y1, lp1])
-            else:
-                ratio = self._error_ratio([yerr], [y], [y1])
+                terms.append((lperr, None, lp, lp1))
+            ratio, y1_bad = self._norms(terms, check=y1)
             accept = ratio <= 1
             if dt > self.max_step:
                 accept = False
             if dt <= self.min_step:
                 accept = True
             if accept:
-                if not bool(torch.isfinite(y1).all()):
+                if y1_bad:
                     raise RuntimeError("non-finite values in state `y`")
                 self.n_accepted += 1
                 interp = (ta, tb, dt, y, y1, ymid, f0, f1,

@@ -11,7 +11,11 @@
 //                      flowfusion/diffusion.py:201,233-238): torchdiffeq performs it as one torch op per term
 //                      (rk_common.py `_runge_kutta_step`), here it is one pass over HBM.
 //
-// Both are pure streaming kernels (roofline: HBM): 16-byte accesses, consecutive lanes on consecutive
+//   ff_scaled_rms      the error / step-size norms of an adaptive step (torchdiffeq: `_compute_error_ratio`,
+//                      `_select_initial_step`; ~10 elementwise and reduction launches and 2-4 host syncs per attempted
+//                      step when written in torch ops) as ONE deterministic reduction launch and one small read-back.
+//
+// All are pure streaming kernels (roofline: HBM): 16-byte accesses, consecutive lanes on consecutive
 // addresses, grid sized to a few workgroups per CU, no LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -79,6 +83,88 @@ __global__ __launch_bounds__(256) void stage_combine_kernel(const CombineArgs a)
     }
 }
 
+// ---- scaled RMS norms of an adaptive step (one launch, one small read-back) ----------------------------------------
+// out[i] = sqrt(mean_k (((num_i[k] - sub_i[k]) / (atol + rtol * max(|s0_i[k]|, |s1_i[k]|)))^2)),  out[n_terms] = 1 if
+// `check` holds a non-finite value else 0.  Deterministic: every block reduces its grid-stride share in a fixed tree,
+// writes one partial per term to the workspace, and the block that arrives last adds the partials up in block order
+// (double accumulation) -- no floating-point atomics, so equal inputs give equal norms and the accept / reject
+// decisions of two runs agree.  Workspace: 1 counter word (left at zero) + kNormBlocks x (FF_NORM_TERMS + 1) doubles.
+constexpr int kNormBlocks = 256;
+
+struct NormArgs {
+    const float* num[FF_NORM_TERMS];
+    const float* sub[FF_NORM_TERMS];
+    const float* s0[FF_NORM_TERMS];
+    const float* s1[FF_NORM_TERMS];
+    long long n[FF_NORM_TERMS];
+    const float* check;
+    long long n_check;
+    int n_terms;
+    float atol, rtol;
+    float* out;
+    unsigned* counter;
+    double* partial;       // [kNormBlocks][FF_NORM_TERMS + 1]
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    }
+    return t;              // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void scaled_rms_kernel(const NormArgs a)
+{
+    __shared__ double sh[4];
+    __shared__ bool last;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int t = 0; t < a.n_terms; ++t) {
+        double acc = 0.0;
+        for (long long i = tid; i < a.n[t]; i += stride) {
+            float v = a.num[t][i];
+            if (a.sub[t]) v -= a.sub[t][i];
+            float sc = fabsf(a.s0[t][i]);
+            if (a.s1[t]) sc = fmaxf(sc, fabsf(a.s1[t][i]));
+            const float q = v / (a.atol + a.rtol * sc);
+            acc += (double)q * (double)q;
+        }
+        const double tot = block_sum(acc, sh);
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
+    }
+    {
+        double bad = 0.0;
+        for (long long i = tid; i < a.n_check; i += stride) {
+            const float v = a.check[i];
+            bad += (v - v == 0.f) ? 0.0 : 1.0;        // NaN or infinity
+        }
+        const double tot = block_sum(bad, sh);
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x <= (unsigned)a.n_terms) {
+        __threadfence();
+        const int t = threadIdx.x < (unsigned)a.n_terms ? (int)threadIdx.x : FF_NORM_TERMS;
+        double tot = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += a.partial[(size_t)b * (FF_NORM_TERMS + 1) + t];
+        if (t < FF_NORM_TERMS) a.out[threadIdx.x] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
+        else a.out[a.n_terms] = tot > 0.0 ? 1.f : 0.f;
+        if (threadIdx.x == 0) *a.counter = 0u;          // ready for the next launch on this stream
+    }
+}
+
 static unsigned stream_grid(long long work_items)
 {
     // a few workgroups per CU (256 CUs) is enough to saturate HBM with 16-byte accesses; never more than needed
@@ -97,6 +183,35 @@ extern "C" int ff_normal_fill(float* out, int64_t batch, int32_t dim, uint64_t s
     const int nblk = (dim + 3) / 4;
     hipLaunchKernelGGL(ff::normal_fill_kernel, dim3(ff::stream_grid(batch * nblk)), dim3(256), 0, (hipStream_t)hip_stream,
                        out, (long long)batch, dim, nblk, (unsigned long long)seed, (long long)sample_offset, noise_index, scale);
+    return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;
+}
+
+extern "C" size_t ff_scaled_rms_workspace_bytes(void)
+{
+    return 16 + (size_t)ff::kNormBlocks * (FF_NORM_TERMS + 1) * sizeof(double);
+}
+
+extern "C" int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float atol, float rtol, const float* check,
+                             int64_t n_check, float* out, void* workspace, void* hip_stream)
+{
+    if (!terms || n_terms < 1 || n_terms > FF_NORM_TERMS || !out || !workspace || n_check < 0 || (n_check > 0 && !check))
+        return FF_ERR_BADARG;
+    ff::NormArgs k;
+    long long most = n_check;
+    for (int t = 0; t < FF_NORM_TERMS; ++t) {
+        const bool on = t < n_terms;
+        if (on && (terms[t].n < 0 || (terms[t].n > 0 && (!terms[t].num || !terms[t].scale0)))) return FF_ERR_BADARG;
+        k.num[t] = on ? terms[t].num : nullptr; k.sub[t] = on ? terms[t].sub : nullptr;
+        k.s0[t] = on ? terms[t].scale0 : nullptr; k.s1[t] = on ? terms[t].scale1 : nullptr;
+        k.n[t] = on ? terms[t].n : 0;
+        if (k.n[t] > most) most = k.n[t];
+    }
+    k.check = check; k.n_check = n_check; k.n_terms = n_terms; k.atol = atol; k.rtol = rtol; k.out = out;
+    k.counter = (unsigned*)workspace;
+    k.partial = (double*)((char*)workspace + 16);
+    long long want = (most + 255) / 256;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > ff::kNormBlocks ? ff::kNormBlocks : want));
+    hipLaunchKernelGGL(ff::scaled_rms_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, k);
     return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;
 }
 

@@ -266,6 +266,30 @@ typedef struct ff_combine_args {
 } ff_combine_args;
 int ff_stage_combine(const ff_combine_args* args, void* hip_stream);
 
+/*
+ * Scaled RMS norms of an adaptive step, in one launch:
+ *     out[i] = sqrt( mean_k ( (num_i[k] - sub_i[k]) / (atol + rtol * max(|scale0_i[k]|, |scale1_i[k]|)) )^2 )   i < n_terms
+ *     out[n_terms] = 1 if `check[0 .. n_check)` holds a NaN or an infinity, else 0
+ * (`sub` and `scale1` may be NULL).  These are the norms torchdiffeq's adaptive solvers take of the tuple state behind
+ * the reference's default `method="dopri5"` (call sites diffusion.py:631-639, 744-752; flow.py:299-303, 371-382):
+ * `_compute_error_ratio` (num = error estimate, scale0 / scale1 = y0 / y1) and `_select_initial_step` (num = y or f or
+ * f1 - f0, scale0 = y); one term per component of the tuple, the caller takes the maximum (the mixed norm).
+ * Deterministic (no floating-point atomics).  All pointers are DEVICE pointers; `out` has n_terms + 1 floats;
+ * `workspace` is ff_scaled_rms_workspace_bytes() bytes of device memory whose first 16 bytes are zero before the first
+ * use (the kernel leaves them zero); one workspace per stream.
+ */
+#define FF_NORM_TERMS 3
+typedef struct ff_norm_term {
+    const float* num;
+    const float* sub;
+    const float* scale0;
+    const float* scale1;
+    int64_t      n;
+} ff_norm_term;
+size_t ff_scaled_rms_workspace_bytes(void);
+int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float atol, float rtol, const float* check,
+                  int64_t n_check, float* out, void* workspace, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

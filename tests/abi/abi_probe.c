@@ -27,6 +27,9 @@ int main(void)
     SZ(ff_combine_args);
     OFF(ff_combine_args, x); OFF(ff_combine_args, k); OFF(ff_combine_args, coef); OFF(ff_combine_args, x_coef);
     OFF(ff_combine_args, out); OFF(ff_combine_args, n);
+    SZ(ff_norm_term);
+    OFF(ff_norm_term, num); OFF(ff_norm_term, sub); OFF(ff_norm_term, scale0); OFF(ff_norm_term, scale1); OFF(ff_norm_term, n);
+    printf("normws %zu\n", ff_scaled_rms_workspace_bytes());
 
     /* plan + packed size for BASELINE config 2's network, from C */
     const int hidden[4] = {256, 256, 256, 256};

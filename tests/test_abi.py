@@ -71,6 +71,7 @@ def test_header_is_c11_and_layouts_match_both_ctypes_mirrors(tmp_path, built_lib
         "ff_mlp_plan_t": (_native.PlanStruct, ns["_Plan"]),
         "ff_ode_args": (_native.OdeArgs, ns["_Args"]),
         "ff_combine_args": (_native.CombineArgs,),
+        "ff_norm_term": (_native.NormTerm,),
     }
     for cname, structs in mirrors.items():
         fields_c = {f for (s, f) in offsets if s == cname}

@@ -182,3 +182,28 @@ def test_stage_combine_and_normal_fill_entry_points():
         assert torch.equal(y, torch.addcmul(x, ks[4], torch.tensor(0.25, device=DEV))) or (y - (x + 0.25 * ks[4])).abs().max() < 1e-6
     with pytest.raises(RuntimeError):
         _native.stage_combine(torch.empty(4), None, [], [])          # CPU tensor
+
+
+def test_scaled_rms_entry_point_matches_torch_and_is_deterministic():
+    """ff_scaled_rms: the adaptive driver's norms in one launch.  Against the torch expressions torchdiffeq uses
+    (`_compute_error_ratio`, `_select_initial_step`), NaN / infinity detection, bitwise run-to-run determinism."""
+    torch.manual_seed(0)
+    atol, rtol = 1e-5, 1e-4
+    for n, m in ((1, 1), (37, 5), (1 << 14, 1 << 10), (3_000_001, 50_000)):
+        err, y0, y1 = (torch.randn(n, device=DEV) * s for s in (1e-4, 1.0, 1.0))
+        le, l0, l1 = (torch.randn(m, device=DEV) * s for s in (1e-3, 3.0, 3.0))
+        f0, f1 = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+        got = _native.scaled_rms([(err, None, y0, y1), (le, None, l0, l1), (f1, f0, y0, None)], atol, rtol, check=y1)
+        exp = [(err / (atol + rtol * torch.max(y0.abs(), y1.abs()))).double().pow(2).mean().sqrt().item(),
+               (le / (atol + rtol * torch.max(l0.abs(), l1.abs()))).double().pow(2).mean().sqrt().item(),
+               ((f1 - f0) / (atol + rtol * y0.abs())).double().pow(2).mean().sqrt().item()]
+        for g, e in zip(got[:3], exp):
+            assert abs(g - e) <= 2e-6 * max(1.0, abs(e)), (n, g, e)
+        assert got[3] == 0.0
+        again = _native.scaled_rms([(err, None, y0, y1), (le, None, l0, l1), (f1, f0, y0, None)], atol, rtol, check=y1)
+        assert again == got                                             # no floating-point atomics
+        for bad in (float("nan"), float("inf"), float("-inf")):
+            y1b = y1.clone()
+            y1b[n // 2] = bad
+            assert _native.scaled_rms([(err, None, y0, y1)], atol, rtol, check=y1b)[1] == 1.0
+    assert _native.scaled_rms([(torch.zeros(8, device=DEV), None, torch.ones(8, device=DEV), None)], 1.0, 0.0)[0] == 0.0
