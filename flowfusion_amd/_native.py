@@ -80,6 +80,8 @@ class OdeArgs(ctypes.Structure):
         ("rng_seed", ctypes.c_uint64),
         ("rng_sample_offset", ctypes.c_int64),
         ("jac_out", ctypes.c_void_p),
+        ("jac_all", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -499,5 +501,51 @@ def mlp_rhs_jac(x: torch.Tensor, cond: Optional[torch.Tensor], wpack: torch.Tens
 
 
 @mlp_rhs_jac.register_fake
+def _(x, cond, wpack, etab, plan, tangent_first, tangent_count, jac):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("flowfusion_amd::mlp_ode_jacobians", mutates_args=("jac",))
+def mlp_ode_jacobians(x: torch.Tensor, cond: Optional[torch.Tensor], wpack: torch.Tensor, etab: torch.Tensor,
+                      plan: List[int], tangent_first: int, tangent_count: int, jac: torch.Tensor) -> torch.Tensor:
+    """Integrate a whole fixed-grid table in exact mode and record the Jacobian of EVERY evaluation row
+    (ff_ode_args.jac_all): fills rows [tangent_first, +count) of ``jac[e, b, j, i] = d rhs_i / d y_j`` and returns the
+    final state [B, D].  The state does not depend on the divergence, so the estimators that need per-evaluation
+    Jacobians (Hutch++, XTrace) can run after the fact, for all rows at once."""
+    if not x.is_cuda:
+        raise RuntimeError("flowfusion_amd::mlp_ode_jacobians needs tensors on the GPU (there is no CPU path)")
+    dev = x.device
+    p = _plan_from_words(plan)
+    B, D = x.shape
+    x_out = torch.empty_like(x)
+    if B == 0:
+        return x_out
+    n_evals = etab.shape[0]
+    if tuple(jac.shape) != (n_evals, B, D, D) or etab.shape[1] != 32 + p.width:
+        raise RuntimeError("mlp_ode_jacobians: jac must be [n_evals, B, D, D] and etab must match the plan")
+    dl = torch.empty(B, dtype=torch.float32, device=dev)
+    a = OdeArgs()
+    a.x_in = _chk(x, "x", dev)
+    a.x_out = x_out.data_ptr()
+    a.cond = _chk(cond, "cond", dev)
+    a.dlogp_out = dl.data_ptr()
+    a.wpack = _chk(wpack, "wpack", dev)
+    a.etab = _chk(etab, "etab", dev)
+    a.batch = B
+    a.n_evals = n_evals
+    a.mode = MODE_EXACT
+    a.tangent_first = tangent_first
+    a.tangent_count = tangent_count
+    a.jac_out = _chk(jac, "jac", dev)
+    a.jac_all = 1
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(a), ctypes.c_void_p(stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_mlp_ode_launch")
+    return x_out
+
+
+@mlp_ode_jacobians.register_fake
 def _(x, cond, wpack, etab, plan, tangent_first, tangent_count, jac):
     return torch.empty_like(x)

@@ -403,6 +403,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.rng_seed = a->rng_seed; ka.rng_sample_offset = a->rng_sample_offset; ka.rng_noise_base = a->rng_noise_base;
     if (a->jac_out && a->mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     ka.jac_out = a->jac_out;
+    ka.jac_all = a->jac_out && a->jac_all ? 1 : 0;
     ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);

@@ -45,6 +45,7 @@ struct KernelArgs {
     long long rng_sample_offset;
     int rng_noise_base;
     float* jac_out;      // [batch, dim, dim] Jacobian of the last evaluation's RHS (exact mode) or NULL
+    int jac_all;         // 1: jac_out is [n_evals, batch, dim, dim] and every evaluation row writes its Jacobian
     float act_p0, act_p1;   // parameters of the hidden activation (FF_ACT_LEAKY_RELU / ELU / SOFTPLUS)
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
 };

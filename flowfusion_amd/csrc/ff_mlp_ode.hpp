@@ -854,9 +854,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             div = is_tangent ? __builtin_fmaf(a_e, ee, b_e * dot) : 0.f;
             // full Jacobian of the last evaluation's right-hand side (unit tangents): tangent column j holds
             // d rhs / d y_j = a_e e_j + b_e dNET/dy_j; stored as row j of jac_out[sample]
-            if (args.jac_out && e == args.n_evals - 1 && is_tangent && col_live && (!COOP || wv == 0)) {
+            if (args.jac_out && (args.jac_all || e == args.n_evals - 1) && is_tangent && col_live && (!COOP || wv == 0)) {
                 const int tj = args.tangent_first + role - 1;
-                float* jp = args.jac_out + ((size_t)sample * D + tj) * D;
+                float* jp = args.jac_out + (((size_t)(args.jac_all ? e : 0) * args.batch + sample) * D + tj) * D;
 #pragma unroll
                 for (int r = 0; r < DREGS; ++r) {
                     const int d = feat_of_reg(TILE, r, qd);

@@ -619,7 +619,19 @@ class ScoreModel(nn.Module):
             y, lp = solver.integrate(float(t_span[0]), float(t_span[1]), x, torch.zeros(B, device=x.device))
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
         else:
-            y, lp = stepper.run_table(x, self._ode_table(t_span, method, options, MODE_EXACT))
+            # fixed grid: one launch per tangent pass records every row's Jacobian; the estimator then runs for all
+            # rows at once with each sample's probes repeated over the rows
+            def div_rows(A, lo, hi):
+                n, b = A.shape[0], A.shape[1]
+                rep = lambda P: P[:, lo:hi].unsqueeze(1).expand(P.shape[0], n, b, D).reshape(P.shape[0], n * b, D)
+                flat = A.reshape(n * b, D, D)
+                if self.hutchpp:
+                    est = trace_estimators.hutchpp(flat, rep(self.S.to(A.device)), rep(self.G.to(A.device)))
+                else:
+                    est = trace_estimators.xtrace(flat, rep(self.O.to(A.device)))
+                return est.reshape(n, b)
+            y, lp = stepper.run_table_recorded(x, self._ode_table(t_span, method, options, MODE_EXACT), div_rows,
+                                               cond=conditional)
         return y, lp.view(-1, 1)
 
     @torch.no_grad()

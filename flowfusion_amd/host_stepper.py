@@ -76,6 +76,46 @@ class RowStepper:
                         lp = lp + float(cout[s]) * kl[s]
         return x, lp
 
+    def run_table_recorded(self, x: torch.Tensor, table: torch.Tensor, div_rows, cond=None, max_bytes: int = 1 << 30):
+        """Fixed-grid integration WITHOUT host stepping: the state never depends on the divergence, so the whole table
+        runs as one fused launch per tangent pass with the Jacobian of every row recorded (ff_ode_args.jac_all), the
+        estimator is evaluated for all rows at once (``div_rows(A [n, b, D, D], lo, hi) -> [n, b]`` for samples
+        lo..hi), and the estimates are combined with the weights the tableau gives each row.  The batch is cut so that
+        a chunk's Jacobians stay under ``max_bytes``.  Returns (x_final, dlogp [B])."""
+        n, D, B = int(table.shape[0]), self.net.dim, int(x.shape[0])
+        ints = table.view(torch.int32)
+        # weight of row e's divergence in the integral: the step-update coefficients applied to the slot it sits in
+        w = torch.zeros(n, dtype=torch.float64)
+        owner = {}
+        for e in range(n):
+            owner[int(ints[e, 4])] = e
+            if int(ints[e, 3]) & FLAG_STEP_END:
+                for s in range(MAX_SLOTS):
+                    c = float(table[e, 16 + s])
+                    if c != 0.0 and s in owner:
+                        w[owner[s]] += c
+        w = w.to(torch.float32).to(x.device)
+        dev = x.device
+        plan = self.net.plan(MODE_EXACT)
+        words = _native.plan_words(plan)
+        wpack = self.net.wpack(dev, MODE_EXACT)
+        tab = table.to(dev)
+        f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+        cond_d = f32(cond) if self.net.cond_dim > 0 else None
+        chunk = max(1, min(B, max_bytes // max(1, n * D * D * 4)))
+        outs, lps = [], []
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            xc = x[lo:hi].contiguous()
+            cc = None if cond_d is None else cond_d[lo:hi].contiguous()
+            jac = torch.empty(n, hi - lo, D, D, dtype=torch.float32, device=dev)
+            for first, count in self.passes:
+                xo = torch.ops.flowfusion_amd.mlp_ode_jacobians(xc, cc, wpack, tab, words, first, count, jac)
+            outs.append(xo)
+            lps.append((w[:, None] * div_rows(jac, lo, hi)).sum(dim=0))
+            self.n_evals += n
+        return torch.cat(outs), torch.cat(lps)
+
     def make_step(self, schedule, sign: float):
         """Step function for ``adaptive.Dopri5`` (same contract as ``FusedNet.make_step``)."""
         def step(y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux):

@@ -165,6 +165,12 @@ typedef struct ff_ode_args {
      * reverse mode (`vjp_fn`, diffusion.py:360-372, 431-443); with the whole matrix on hand those
      * estimators are small per-sample linear algebra (flowfusion_amd/trace_estimators.py). */
     float*       jac_out;
+    int32_t      jac_all;    /* 0: jac_out = [batch][dim][dim], the Jacobian of the LAST evaluation row (above);
+                                1: jac_out = [n_evals][batch][dim][dim], the Jacobian of EVERY row.  The state never
+                                depends on the divergence, so one launch can integrate a whole fixed-grid table and
+                                hand back everything the Hutch++ / XTrace estimators need; they are then evaluated
+                                for all rows at once and combined with the tableau's weights by the caller. */
+    int32_t      reserved0;
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

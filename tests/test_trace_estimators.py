@@ -116,3 +116,53 @@ def test_row_stepper_reproduces_reference_log_density(name, built_library):
     everyone = torch.ones(xs.shape[0], dtype=torch.bool)
     _close(y, ry.float(), everyone.repeat_interleave(xs.shape[1]), 2e-4)
     _close(lp, rlp, everyone, 2e-4)
+
+
+def test_thin_qr_follows_lapack():
+    """trace_estimators.thin_qr (batched Householder in LAPACK's conventions) against torch.linalg.qr on the CPU
+    (LAPACK geqrf + orgqr, what the reference calls): the same Q and R to rounding -- also for rank-deficient sketches
+    (two +-1 probes equal up to sign: the reflectors still complete r orthonormal columns), and hence the same
+    Hutch++ / XTrace estimates."""
+    from flowfusion_amd import trace_estimators as TE
+    torch.manual_seed(0)
+    for D, r in ((16, 1), (16, 4), (5, 5), (32, 8), (2, 2)):
+        Y = torch.randn(50, D, r, dtype=torch.float64)
+        Y[3, :, r - 1] = -Y[3, :, 0]                                    # a dependent column
+        if D > 2:
+            Y[7, 1:, 0] = 0.0                                           # nothing below the diagonal: H = I
+        Q, R = TE.thin_qr(Y)
+        Qh, Rh = torch.linalg.qr(Y, mode="reduced")
+        eye = torch.eye(r, dtype=torch.float64)
+        assert (Q.transpose(1, 2) @ Q - eye).abs().max() < 1e-12 and (Q @ R - Y).abs().max() < 1e-12
+        assert (torch.tril(R, -1)).abs().max() == 0
+        ok = torch.ones(50, dtype=torch.bool)
+        ok[3] = r == 1                                                   # the completion of a singular sketch is compared below
+        assert (Q[ok] - Qh[ok]).abs().max() < 1e-11 and (R[ok] - Rh[ok]).abs().max() < 1e-11
+    A = torch.randn(40, 6, 6, dtype=torch.float64)
+    S, G, O = (torch.sign(torch.randn(n, 40, 6, dtype=torch.float64)) for n in (2, 3, 4))
+    S[1, 5] = -S[0, 5]                                                   # rank-deficient sketches
+    O[3, 9] = O[0, 9]
+    own = (TE.hutchpp(A, S, G), TE.xtrace(A, O))
+    orig = TE.thin_qr
+    try:
+        TE.thin_qr = lambda Y: torch.linalg.qr(Y, mode="reduced")
+        ref = (TE.hutchpp(A, S, G), TE.xtrace(A, O))
+    finally:
+        TE.thin_qr = orig
+    # Where two probes of a sample coincide up to sign the sketch is singular: the completing column is then a
+    # normalised rounding residue -- noise in LAPACK as much as here -- and the estimate is ill-posed.  Everywhere else
+    # the two factorisations must give the same numbers.
+    def well_posed(P):
+        Pc = P.permute(1, 2, 0)
+        gram = (Pc.transpose(1, 2) @ Pc).abs() / P.shape[2]
+        off = gram - torch.diag_embed(torch.diagonal(gram, 0, 1, 2))
+        return off.amax(dim=(1, 2)) < 1.0 - 1e-9
+    ws, wo = well_posed(S), well_posed(O)
+    assert not ws[5] and not wo[9] and ws.sum() >= 30
+    assert (own[0][ws] - ref[0][ws]).abs().max() < 1e-9
+    assert (own[1][wo] - ref[1][wo]).abs().max() < 1e-8
+    # full-rank request (r = D): whatever the completion, Q is a whole orthonormal basis and Hutch++ IS the trace
+    S6 = torch.sign(torch.randn(6, 40, 6, dtype=torch.float64))
+    S6[3, 2] = S6[1, 2]
+    est = TE.hutchpp(A, S6, G)
+    assert (est - torch.diagonal(A, 0, 1, 2).sum(-1)).abs().max() < 1e-9
