@@ -190,7 +190,8 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
             f"activation={act[0]}: "
-            "compiled shapes cover dim<=64, cond_dim<=32, hidden width<=512")
+            "compiled shapes cover dim<=128, cond_dim<=64, hidden width<=1024 (SiLU; other activations: dim<=64, "
+            "cond_dim<=16, width<=512)")
     if rc != FF_OK:
         raise _err(rc, "ff_mlp_plan")
     return p

@@ -332,7 +332,8 @@ extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
     int nt, unit;
     int rc = tangents_of_mode(mode, plan->dim, plan->tile, &nt, &unit);
     if (rc) return rc;
-    return 4 * (plan->tile / (1 + nt));
+    const bool wide = ff::g_kernels[plan->kernel_id].launch == nullptr;      // a tile per workgroup
+    return (wide ? 1 : 4) * (plan->tile / (1 + nt));
 }
 
 // FF_PREC_BF16X3 launch: state-only / Hutchinson integration of a table without noise rows
@@ -419,11 +420,14 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     // (two workgroups of a <= 256-wide twin share a CU: it still wins at three quarters of a chip's worth of tiles)
     bool coop = k.launch_coop != nullptr && tiles <= (plan->width <= 256 ? 768 : 512);
     if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
+    const bool wide = k.launch == nullptr;                 // wide catch-all: cooperative at every batch size, one exchange buffer
+    if (wide) coop = true;
     const long long grid = coop ? tiles : (tiles + 3) / 4;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
     const unsigned slots = ff::kSlots * (plan->dregs / 4) * 64 * 16;
     const unsigned kh = (plan->width / 32) * ff::tile_rb(plan->tile);                 // operand registers of a hidden layer
-    const unsigned lds = coop ? slots + 2u * (kh / 4) * 64 * 16 : 4u * slots;
+    const unsigned lds = coop ? slots + (wide ? 1u : 2u) * (kh / 4) * 64 * 16 : 4u * slots;
+    if (lds > 160u * 1024u) return FF_ERR_UNSUPPORTED;
     const int herr = (coop ? k.launch_coop : k.launch)(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
     if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
     return FF_OK;

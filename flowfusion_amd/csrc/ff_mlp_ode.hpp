@@ -413,9 +413,17 @@ FF_HD constexpr int act_group_at(const LayerGeom& L, int phys, int gpb, int M, i
 // to give every SIMD a tile of its own.  Same packed weights, same fp32 FMA chains in the same order (results equal the
 // one-wavefront kernel's bit for bit); state, stage slots and bookkeeping are replicated in the four wavefronts and
 // wavefront 0 writes the outputs.  The launcher picks the twin by batch size (ff_api.cpp).
-template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, int ACT = 0, bool COOP = false>
+//
+// WIDE (implies COOP; networks wider than 512 or with more than 64 dimensions / 32 conditional inputs, at ANY batch
+// size): the operand vector of a hidden layer no longer fits a wavefront's registers beside its accumulators, so the
+// B operands are read from the LDS exchange buffer group by group (one ds_read_b128 per 4 operand registers, one group
+// ahead of the MFMAs that use it) instead of all at once after the exchange; one exchange buffer and a second barrier
+// per layer (everybody has finished reading before anybody overwrites).  Same packed layout and FMA chains.
+template <int TILE, int H, int DREGS, int CREGS, bool TANGENTS, int WPS, int RING, int ACT = 0, bool COOP = false,
+          bool WIDE = false>
 __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args)
 {
+    static_assert(!WIDE || COOP, "the wide variant is a cooperative kernel");
     static_assert(kChunkPad % RING == 0, "ring must divide the chunk padding");
     static_assert(!COOP || (H / 32) % 4 == 0, "the cooperative twin splits the blocks of a layer four ways");
     typedef Tile<TILE> T;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     extern __shared__ __attribute__((aligned(16))) f32x4 lds_slots[];
     // (cooperative twin: one copy -- the four wavefronts hold the same tile and write the same values)
     f32x4* const ks = lds_slots + (size_t)(COOP ? 0 : (threadIdx.x >> 6)) * kSlots * R4 * 64 + lane;
-    f32x4* const exch = lds_slots + (size_t)kSlots * R4 * 64 + lane;         // COOP: 2 x (KH / 4) x 64 exchange slots
+    f32x4* const exch = lds_slots + (size_t)kSlots * R4 * 64 + lane;         // COOP: 2 (WIDE: 1) x (KH / 4) x 64 exchange slots
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         for (int p = 0; p < T::PHYS; ++p)
             ring[i][p] = sload(ws, lane16, (COOP ? coop_byte(CG1, 0, i, NBW, ob0) : i * CB) + p * 1024);
 
-    float P[KH];
+    float P[WIDE ? 4 : KH];          // operand registers of a hidden layer (WIDE: they stay in LDS)
     // Accumulators of the hidden layers.  They always hold the bias of the layer about to run: a block is
     // refilled with the next layer's bias (straight from the bias stream, in accumulator order) as soon as its
     // pre-activations have been consumed, so the MFMA chain adds the bias and the activation path does not.
@@ -626,20 +634,31 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 static_assert(NV % RING == 0, "visiting lists are multiples of the ring length");
                 constexpr int OUT_LAST = (DREGS * T::NQ - (NOB_OUT - 1) * 32 + TILE - 1) / TILE;
                 constexpr int LAST_PHYS = KIND == 2 ? (OUT_LAST < T::PHYS ? OUT_LAST : T::PHYS) : T::PHYS;
+                // WIDE: the operands of group g come from the exchange buffer, requested one group ahead
+                constexpr bool LDS_B = WIDE && KIND != 0;
+                f32x4 bq = f32x4{0.f, 0.f, 0.f, 0.f}, bq_next = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (LDS_B) bq_next = exch[0];
                 static_for<NV>([&](auto ii) {
                     constexpr int i = decltype(ii)::value;
                     constexpr int slot = i % RING, g = i / NM, j = i % NM;
                     if constexpr (g < G.G) {
+                        if constexpr (LDS_B && j == 0) {
+                            bq = bq_next;
+                            if constexpr (g + 1 < G.G) bq_next = exch[(g + 1) * 64];
+                        }
                         static_for<4>([&](auto qq) {
                             constexpr int q = decltype(qq)::value;
+                            float bop;
+                            if constexpr (LDS_B) bop = bq[q];
+                            else bop = Bop[4 * g + q];
                             static_for<T::PHYS>([&](auto pp) {
                                 constexpr int p = decltype(pp)::value;
                                 if constexpr (KIND == 2 && j == NM - 1 && p >= LAST_PHYS) {
                                     if constexpr (g == 0 && q == 0) acc[j].v[p] = T::zero();
                                 } else if constexpr (KIND == 2 && g == 0 && q == 0)
-                                    acc[j].v[p] = T::mfma(ring[slot][p][q], Bop[4 * g + q], T::zero());
+                                    acc[j].v[p] = T::mfma(ring[slot][p][q], bop, T::zero());
                                 else
-                                    acc[j].v[p] = T::mfma(ring[slot][p][q], Bop[4 * g + q], acc[j].v[p]);
+                                    acc[j].v[p] = T::mfma(ring[slot][p][q], bop, acc[j].v[p]);
                             });
                         });
                     }
@@ -657,7 +676,8 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             };
             // activate this wavefront's blocks and trade them for everybody else's: P <- all KH operand registers
             auto coop_exchange = [&](const BlockAcc<TILE> (&acc)[NBW], int buf) __attribute__((always_inline)) {
-                f32x4* const xb = exch + (size_t)buf * (KH / 4) * 64;
+                f32x4* const xb = exch + (size_t)(WIDE ? 0 : buf) * (KH / 4) * 64;
+                if constexpr (WIDE) __syncthreads();         // one buffer: the layer that read it has finished everywhere
                 static_for<NBW>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
                     static_for<RBQ>([&](auto rr) {
@@ -673,11 +693,13 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                     });
                 });
                 __syncthreads();
+                if constexpr (!WIDE) {
 #pragma unroll
-                for (int k4 = 0; k4 < KH / 4; ++k4) {
-                    const f32x4 v = xb[k4 * 64];
+                    for (int k4 = 0; k4 < KH / 4; ++k4) {
+                        const f32x4 v = xb[k4 * 64];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) P[4 * k4 + i] = v[i];
+                        for (int i = 0; i < 4; ++i) P[4 * k4 + i] = v[i];
+                    }
                 }
             };
             auto next_hidden_or_out = [&](int l_next, auto kk, auto sl) __attribute__((always_inline)) {

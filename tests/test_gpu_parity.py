@@ -233,7 +233,7 @@ def test_empty_batch_and_nan_flag():
 
 def test_unsupported_shapes_raise_on_gpu():
     from flowfusion_amd import flow as Fm
-    f = Fm.ODEFlow(64, [1024] * 2).to(DEV).eval()                 # wider than any compiled kernel
+    f = Fm.ODEFlow(64, [2048] * 2).to(DEV).eval()                 # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
         f.sample(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
 

@@ -121,3 +121,42 @@ def test_small_batches_take_the_twin_by_default_and_are_faster():
     print(f"\n[small batch] 2048 x 100-step RK4: default {t_def * 1e3:.2f} ms, one-wavefront kernel {t_one * 1e3:.2f} ms "
           f"({t_one / t_def:.2f}x)")
     assert t_def < 0.6 * t_one
+
+
+@pytest.mark.parametrize("D,C,units,sde", [(16, 0, [1024, 1024], "VPSDE"), (100, 40, [300, 700], "VESDE"), (64, 50, [512], "VPSDE")])
+def test_wide_catch_all_kernels_against_oracle(D, C, units, sde):
+    """Beyond 512 wide / 64 dimensions / 32 conditional inputs the plan lands on the wide catch-alls (a tile per
+    workgroup at every batch size, hidden operands streamed from LDS): sampling, Hutchinson and exact log-density, and
+    Euler-Maruyama against the oracle, and batch-shape invariance across the workgroup boundary."""
+    from flowfusion_amd import _native
+    from tests.test_gpu_parity import LOGP_TOL, STATE_TOL, _logp_err, _state_err
+    sm, so32, so64 = _seeded_score_model(D, C, units, sde, sde == "VPSDE", 29)
+    assert _native.kernel_name(sm._net().plan(0)).endswith("_wide")
+    B = 70
+    torch.manual_seed(3)
+    base = torch.randn(B, D)
+    cond = torch.randn(B, C) if C else None
+    cd = None if cond is None else cond.to(DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 6}
+    x, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cd, method="rk4", options=opts)
+    ref = so64.sample_ode_from_base(base.double(), None if cond is None else cond.double(), "rk4", opts).float()
+    assert _state_err(x, ref) < STATE_TOL
+    xs, _ = sm.sample_ode_from_base(base[10:33].to(DEV), conditional=None if cd is None else cd[10:33].contiguous(),
+                                    method="rk4", options=opts)
+    assert torch.equal(xs, x[10:33])
+    sm.hutch = True
+    x0 = base[:24] * 0.5
+    c24 = None if cd is None else cd[:24].contiguous()
+    torch.manual_seed(4)
+    lp = sm.log_prob(x0.to(DEV), conditional=c24, method="midpoint", options=opts)
+    ref = so64.log_prob(x0.double(), None if cond is None else cond[:24].double(), "midpoint", opts, "hutch", sm.e.cpu().double()).float()
+    assert _logp_err(lp, ref) < LOGP_TOL
+    if D <= 64:                                      # exact trace: D unit tangents in passes of 15
+        sm.hutch = False
+        lp = sm.log_prob(x0[:6].to(DEV), conditional=None if c24 is None else c24[:6].contiguous(), method="euler", options=opts)
+        ref = so64.log_prob(x0[:6].double(), None if cond is None else cond[:6].double(), "euler", opts, "exact").float()
+        assert _logp_err(lp, ref) < LOGP_TOL
+    noise = torch.randn(5, B, D)
+    it = iter(noise)
+    s = sm._sample_sde_from(base.to(DEV), lambda like: next(it).to(DEV), cd, steps=5)
+    assert _state_err(s, so32.sample_sde(base, list(noise), cond, steps=5)) < STATE_TOL

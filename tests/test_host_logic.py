@@ -54,11 +54,17 @@ def test_plan_selection_and_errors(built_library):
     p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
     assert p.tile == 16 and _native.samples_per_workgroup(p, MODE_EXACT) == 4
     with pytest.raises(NotImplementedError):
-        _native.make_plan(64, 0, [1024] * 2, MODE_STATE)          # wider than any compiled kernel
+        _native.make_plan(64, 0, [2048] * 2, MODE_STATE)          # wider than any compiled kernel
     with pytest.raises(NotImplementedError):
-        _native.make_plan(80, 0, [64], MODE_STATE)                # more dimensions than any compiled kernel
+        _native.make_plan(130, 0, [64], MODE_STATE)               # more dimensions than any compiled kernel
     with pytest.raises(NotImplementedError):
-        _native.make_plan(4, 33, [64], MODE_STATE)                # more conditional inputs than any compiled kernel
+        _native.make_plan(4, 65, [64], MODE_STATE)                # more conditional inputs than any compiled kernel
+    # beyond 512 wide / 64 dimensions / 32 conditional inputs: the wide catch-alls (a tile per workgroup at every batch size)
+    p = _native.make_plan(64, 0, [1024] * 2, MODE_STATE)
+    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 1024, 16, 8) and _native.kernel_name(p).endswith("_wide")
+    assert _native.samples_per_workgroup(p, MODE_STATE) == 16
+    p = _native.make_plan(100, 40, [300], MODE_HUTCH)
+    assert (p.width, p.dregs, p.cregs) == (1024, 32, 16) and _native.samples_per_workgroup(p, MODE_HUTCH) == 8
     # launch argument checking happens before any HIP call
     bad = _native.OdeArgs()
     rc = built_library.ff_mlp_ode_launch(ctypes.byref(p), ctypes.byref(bad), None)
