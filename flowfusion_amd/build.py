@@ -30,7 +30,8 @@ ARCH = "gfx950"
 #   H        hidden width on chip;  DREGS / CREGS state / conditional registers per lane
 #            (TILE 32: dim <= 2*DREGS; TILE 16: dim <= 4*DREGS)
 #   TANGENTS divergence-capable;  WPS waves per SIMD (launch bound);  RING weight chunks in flight
-#   ACT      FF_ACT_* code of the hidden activation compiled in: 0 = SiLU (the reference default), 1..8 the others
+#   ACT      FF_ACT_* code of the hidden activation compiled in: 0 = SiLU (the reference default), 1..8 the others,
+#            9 = any non-SiLU activation, chosen at run time
 INSTANCES = [
     # narrow networks: 32 samples per wavefront, one wavefront per SIMD
     (32, h, d, c, t, 1, 8, 0)
@@ -60,12 +61,15 @@ INSTANCES = [
     (16, 512, 16, 8, t, 1, 4, 0) for t in (0, 1)
 ] + [
     # non-default activations (`activation=` of the reference constructors; ACT = FF_ACT_* code 1..8, compiled in and
-    # staged like SiLU): one covering shape per width and activation
+    # staged like SiLU): one covering shape per width <= 256 and activation
     (tile, h, d, c, t, wps, ring, act)
     for act in range(1, 9)
-    for (tile, h, d, c, wps, ring) in ((32, 64, 16, 8, 1, 8), (32, 128, 16, 8, 1, 8), (16, 256, 8, 4, 2, 8),
-                                       (16, 512, 16, 4, 1, 4))
+    for (tile, h, d, c, wps, ring) in ((32, 64, 16, 8, 1, 8), (32, 128, 16, 8, 1, 8), (16, 256, 8, 4, 2, 8))
     for t in (0, 1)
+] + [
+    # ... and at width 512, where one kernel takes two minutes to compile, ONE instantiation per mode that chooses the
+    # activation at run time (ACT = 9)
+    (16, 512, 16, 4, t, 1, 4, 9) for t in (0, 1)
 ]
 
 # Wide catch-alls (kernel template WIDE: cooperative at every batch size, hidden operands read from LDS): networks up
@@ -291,15 +295,30 @@ const int g_n_split_kernels = {len(SPLIT_INSTANCES)};
     return files
 
 
-def _deps_hash(public: bool) -> str:
-    """Hash of the headers a translation unit can see: the kernel headers under csrc/, plus -- for the two files
-    that implement the C ABI -- include/flowfusion_amd.h (the generated kernel units never include it, so a change
-    to the public header does not recompile 46 kernels)."""
+_INCLUDE_RE = None
+
+
+def _local_includes(path: Path, seen: dict) -> None:
+    """Transitive closure of the `#include "..."` headers of `path` that live under csrc/ or include/."""
+    global _INCLUDE_RE
+    import re
+    if _INCLUDE_RE is None:
+        _INCLUDE_RE = re.compile(r'^\s*#\s*include\s*"([^"]+)"', re.M)
+    for name in _INCLUDE_RE.findall(path.read_text()):
+        for base in (CSRC, ROOT / "include"):
+            h = base / name
+            if h.exists() and h not in seen:
+                seen[h] = True
+                _local_includes(h, seen)
+
+
+def _deps_hash(src: Path) -> str:
+    """Hash of the project headers a translation unit actually includes (transitively): a change to the split-precision
+    kernel does not recompile the f32 kernels, a change to the public header only the two files that implement it."""
+    seen: dict = {}
+    _local_includes(src, seen)
     h = hashlib.sha256()
-    deps = sorted(list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp")))
-    if public:
-        deps.append(ROOT / "include" / "flowfusion_amd.h")
-    for p in deps:
+    for p in sorted(seen):
         h.update(p.name.encode())
         h.update(p.read_bytes())
     return h.hexdigest()
@@ -331,11 +350,12 @@ def build(verbose: bool = False, jobs: int | None = None) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     LIBDIR.mkdir(parents=True, exist_ok=True)
     srcs = _gen_sources()
-    hashes = {False: _deps_hash(False), True: _deps_hash(True)}
-    uses_public = lambda s: s.parent == CSRC
     jobs = jobs or min(8, os.cpu_count() or 1)
+    # the slowest translation units (512- and 1024-wide kernels: two minutes each) first, so they do not trail the pool
+    order = sorted(srcs, key=lambda s: (0 if ("_h512_" in s.name or "_h1024_" in s.name) else 1, s.name))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, hashes[uses_public(s)], verbose), srcs))
+        done = dict(zip(order, ex.map(lambda s: _compile(s, _deps_hash(s), verbose), order)))
+    objs = [done[s] for s in srcs]
     stamp = hashlib.sha256("".join(sorted(o.name for o in objs)).encode()).hexdigest()
     stamp_file = PKG / "_build" / "link.stamp"
     if LIB.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:

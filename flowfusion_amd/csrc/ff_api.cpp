@@ -110,7 +110,8 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
         const ff::KernelEntry& k = ff::g_kernels[i];
         const int need_d = ff::regs_for(k.tile, dim);
         const int need_c = cond_dim > 0 ? ff::regs_for(k.tile, cond_dim) : 0;
-        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t || k.act != activation) continue;
+        if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t ||
+            !(k.act == activation || (k.act == 9 && activation != FF_ACT_SILU))) continue;
         if (pin_tile && k.tile != pin_tile) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
@@ -149,7 +150,7 @@ static bool plan_ok(const ff_mlp_plan_t* p)
     const ff::KernelEntry& k = ff::g_kernels[p->kernel_id];
     const int per_reg = 64 / k.tile;
     return k.H == p->width && k.dregs == p->dregs && k.cregs == p->cregs && k.tile == p->tile && p->n_hidden >= 1 &&
-           p->activation >= 0 && p->activation < FF_ACT_COUNT && p->activation == k.act &&
+           p->activation >= 0 && p->activation < FF_ACT_COUNT && (p->activation == k.act || (k.act == 9 && p->activation != FF_ACT_SILU)) &&
            p->dim >= 1 && p->dim <= per_reg * p->dregs && p->cond_dim >= 0 && p->cond_dim <= per_reg * p->cregs;
 }
 
@@ -405,7 +406,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if (a->jac_out && a->mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     ka.jac_out = a->jac_out;
     ka.jac_all = a->jac_out && a->jac_all ? 1 : 0;
-    ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
+    ka.act_kind = plan->activation; ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;

@@ -46,6 +46,7 @@ struct KernelArgs {
     int rng_noise_base;
     float* jac_out;      // [batch, dim, dim] Jacobian of the last evaluation's RHS (exact mode) or NULL
     int jac_all;         // 1: jac_out is [n_evals, batch, dim, dim] and every evaluation row writes its Jacobian
+    int act_kind;        // FF_ACT_* (read by the run-time-choice instantiations only)
     float act_p0, act_p1;   // parameters of the hidden activation (FF_ACT_LEAKY_RELU / ELU / SOFTPLUS)
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
 };

@@ -146,6 +146,7 @@ struct ActGroup {
 struct ActSpec {
     float p0, p1;
     float ip0;      // 1 / p0 (softplus divides by beta: one division per kernel instead of one per element)
+    int kind;       // FF_ACT_* code, read only by the run-time-choice instantiations (ACT = kActAny)
 };
 
 // Activations other than SiLU (template parameter ACT = FF_ACT_* code, compiled in): value h = act(a) and slope
@@ -250,14 +251,41 @@ __device__ __forceinline__ void act_stage_kind(ActGroup& g, float* __restrict__ 
         }
     }
 }
+constexpr int kActAny = 9;      // ACT code of the instantiations that choose the activation at run time (ActSpec::kind)
 template <bool TANGENTS, int ACT, int STAGE>
 __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, bool is_tangent,
                                           int value_lane_bytes, const ActSpec& spec)
 {
-    if constexpr (ACT != 0) {
+    if constexpr (ACT == kActAny) {
+        // Run-time choice (one instantiation per mode serves every non-SiLU activation at width 512, where a kernel
+        // takes minutes to compile): the chosen kind's stages 0..3 run back to back in stage 3 -- a wave-uniform
+        // switch, not latency-tuned -- and the common select follows in stage 4.
+        if constexpr (STAGE == 3) {
+            auto run = [&](auto kind) __attribute__((always_inline)) {
+                constexpr int K = decltype(kind)::value;
+                act_stage_kind<TANGENTS, K, 0>(g, dst, is_tangent, value_lane_bytes, spec);
+                act_stage_kind<TANGENTS, K, 1>(g, dst, is_tangent, value_lane_bytes, spec);
+                act_stage_kind<TANGENTS, K, 2>(g, dst, is_tangent, value_lane_bytes, spec);
+                act_stage_kind<TANGENTS, K, 3>(g, dst, is_tangent, value_lane_bytes, spec);
+            };
+            switch (spec.kind) {
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            case 4: run(std::integral_constant<int, 4>{}); break;
+            case 5: run(std::integral_constant<int, 5>{}); break;
+            case 6: run(std::integral_constant<int, 6>{}); break;
+            case 7: run(std::integral_constant<int, 7>{}); break;
+            default: run(std::integral_constant<int, 8>{}); break;
+            }
+        } else if constexpr (STAGE == 4) {
+            act_stage_kind<TANGENTS, 8, 4>(g, dst, is_tangent, value_lane_bytes, spec);     // the select is the same for every kind
+        }
+        return;
+    } else if constexpr (ACT != 0) {
         act_stage_kind<TANGENTS, ACT, STAGE>(g, dst, is_tangent, value_lane_bytes, spec);
         return;
-    }
+    } else {
 #ifdef FF_DEBUG_LINEAR_ACT      // timing experiment only: identity activation (wrong results)
     if constexpr (STAGE == 3) {
 #pragma unroll
@@ -288,6 +316,7 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
             if constexpr (TANGENTS) dst[i] = g.pre[i] * (is_tangent ? __builtin_bit_cast(float, g.dv[i]) : g.r[i]);
         }
     }
+    }   // SiLU
 }
 constexpr int kActStages = 5;
 constexpr int kTailSlots = 2 * kActStages;   // slots granted after a layer's last MFMA
@@ -446,7 +475,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wavefront of the workgroup
     const int D = args.dim;
     const int C = args.cond_dim;
-    const ActSpec aspec = {args.act_p0, args.act_p1, ACT == 6 ? 1.0f / args.act_p0 : 0.f};
+    const ActSpec aspec = {args.act_p0, args.act_p1, (ACT == 6 || ACT == kActAny) ? 1.0f / args.act_p0 : 0.f, args.act_kind};
 
     // ---- column roles -----------------------------------------------------------------
     long long sample;

@@ -61,7 +61,16 @@ __device__ __forceinline__ void sfor(F&& f)
 
 __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c)
 {
+#ifdef FF_SPLIT_MFMA16          // timing experiment only: the same FLOPs as two 16x16x32 MFMAs (wrong results)
+    f32x4 lo = f32x4{c[0], c[1], c[2], c[3]}, hi = f32x4{c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+    c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 // one group: the six products of (w_hi, w_mid, w_lo) x (x_hi, x_mid, x_lo) that matter
 __device__ __forceinline__ void group6(f32x16& acc, const u32x4 (&w)[3], const u32x4 (&b)[3])

@@ -15,7 +15,8 @@ struct KernelEntry {
     int dregs;      // state registers  (covers dim <= dregs * 64/tile)
     int cregs;      // conditional registers
     int tangents;   // 1: divergence-capable instantiation
-    int act;        // FF_ACT_* code of the hidden activation this instantiation has compiled in (0 = SiLU)
+    int act;        // FF_ACT_* code of the hidden activation this instantiation has compiled in (0 = SiLU; 9 = any
+                    // non-SiLU activation, chosen at run time)
     LaunchFn launch;
     const char* name;
     LaunchFn launch_coop;   // cooperative twin for small batches (one tile per workgroup, ff_mlp_ode.hpp COOP) or NULL
