@@ -130,10 +130,11 @@ def split_precision_record(device, z, opts, steps, warmup, f32_x):
     kms = sum(a.elapsed_time(b) for a, b in ev) / steps
     n_evals = 4 * N_STEPS
     flop_alg = 2.0 * mac_per_eval(DIM, UNITS) * n_evals * B
-    # executed: 6 bf16 MFMAs per (32-row tile, 16-wide k-step) -- first layer 1 k-step x 8 tiles, hidden 16 x 8, output
-    # 16 x 1 -- of 2 x 32 x 32 x 16 FLOP each, per 32 samples and evaluation
-    mfma_per_eval = 6 * (8 * 1 + 3 * 8 * 16 + 16)
-    flop_exec = mfma_per_eval * 32768.0 * n_evals * (B / 32)
+    # executed: 12 bf16 MFMAs (six products x two column blocks of 16 samples) per (16-row tile, 32-wide k-step) -- first
+    # layer 16 tiles x 1 k-step, hidden 16 x 8 each, output 1 x 8 -- of 2 x 16 x 16 x 32 FLOP each, per 32 samples and
+    # evaluation
+    mfma_per_eval = 12 * (16 * 1 + 3 * 16 * 8 + 8)
+    flop_exec = mfma_per_eval * 16384.0 * n_evals * (B / 32)
     err = float((x - f32_x).abs().max() / f32_x.abs().max())
     return {
         "metric": "samples/sec (whole node), 16-dim VP-SDE 100-step RK4", "value": B * steps / elapsed, "unit": "samples/s",

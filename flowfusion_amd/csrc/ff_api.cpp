@@ -52,20 +52,20 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
         if (hidden_widths[i] < 1) return FF_ERR_BADARG;
         if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
     }
-    const int need_t = mode != FF_MODE_STATE, need_k = cond_dim > 0 ? 2 : 1;
+    if (wmax > ff::split::kWidth) return FF_ERR_UNSUPPORTED;
+    const int need_t = mode != FF_MODE_STATE;
     int best = -1;
     for (int i = 0; i < ff::g_n_split_kernels; ++i) {
         const ff::SplitKernelEntry& k = ff::g_split_kernels[i];
-        if (32 * k.nt < wmax || k.k1s != need_k || k.n_hidden != n_hidden || k.tangents != need_t) continue;
-        if (best < 0 || k.nt < ff::g_split_kernels[best].nt) best = i;
+        if (k.n_hidden == n_hidden && k.tangents == need_t) best = i;
     }
     if (best < 0) return FF_ERR_UNSUPPORTED;
     memset(plan, 0, sizeof(*plan));
     plan->dim = dim;
     plan->cond_dim = cond_dim;
     plan->n_hidden = n_hidden;
-    plan->width = 32 * ff::g_split_kernels[best].nt;
-    plan->dregs = 8;                                   // 16 dimensions over the two lane halves
+    plan->width = ff::split::kWidth;
+    plan->dregs = 8;                                   // 4 dimensions x 2 column blocks per lane
     plan->cregs = cond_dim > 0 ? 8 : 0;
     plan->kernel_id = best;
     plan->tile = 32;
@@ -138,9 +138,9 @@ static bool plan_ok_split(const ff_mlp_plan_t* p)
 {
     if (!p || p->precision != FF_PREC_BF16X3 || p->kernel_id < 0 || p->kernel_id >= ff::g_n_split_kernels) return false;
     const ff::SplitKernelEntry& k = ff::g_split_kernels[p->kernel_id];
-    return p->width == 32 * k.nt && p->tile == 32 && p->dregs == 8 && p->cregs == (k.k1s > 1 ? 8 : 0) &&
+    return p->width == ff::split::kWidth && p->tile == 32 && p->dregs == 8 && p->cregs == (p->cond_dim > 0 ? 8 : 0) &&
            p->n_hidden == k.n_hidden && p->activation == FF_ACT_SILU && p->dim >= 1 && p->dim <= 16 &&
-           p->cond_dim >= 0 && p->cond_dim <= 16 && (p->cond_dim > 0) == (k.k1s > 1);
+           p->cond_dim >= 0 && p->cond_dim <= 16;
 }
 
 static bool plan_ok(const ff_mlp_plan_t* p)
@@ -169,8 +169,7 @@ extern "C" const char* ff_plan_kernel_name(const ff_mlp_plan_t* plan)
 extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
 {
     if (plan_ok_split(plan)) {
-        const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
-        return ff::split::total_words(k.nt, k.k1s, k.n_hidden);
+        return ff::split::total_words(plan->n_hidden);
     }
     if (!plan_ok(plan)) return 0;
     return plan_layout(plan).total_floats;
@@ -193,17 +192,16 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
                        const int* hidden_widths, int in_features0, int x_col0, int c_col0, float* out)
 {
     namespace sp = ff::split;
-    const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
-    const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden, NT = k.nt;
+    const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden;
     uint32_t* words = (uint32_t*)out;
-    memset(out, 0, sp::total_words(NT, k.k1s, NH) * 4);
+    memset(out, 0, sp::total_words(NH) * 4);
     size_t group = 0;                                  // running group index in the stream
-    // one group: fragments [hi, mid, lo] of row tile t; element (lane half h, j) multiplies input column col(h, j)
-    auto put_group = [&](const float* Wl, int rows, int ld, int t, auto col) {
+    // one group: fragments [hi, mid, lo] of 16-row tile rt; element (quad q, j) multiplies input column col(q, j)
+    auto put_group = [&](const float* Wl, int rows, int ld, int rt, auto col) {
         uint32_t* g = words + group * (sp::kGroupFrags * sp::kFragBytes / 4);
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
-                const int row = 32 * t + (lane & 31), c = col(lane >> 5, j);
+                const int row = 16 * rt + (lane & 15), c = col(lane >> 4, j);
                 const float v = (row < rows && c >= 0) ? Wl[(size_t)row * ld + c] : 0.f;
                 float r1, r2, r3;
                 const uint16_t part[3] = {bf16_top(v, &r1), bf16_top(r1, &r2), bf16_top(r2, &r3)};
@@ -214,40 +212,36 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
             }
         ++group;
     };
-    // layer 1: k-step 0 = state dimensions, k-step 1 = conditional inputs
-    for (int s = 0; s < k.k1s; ++s)
-        for (int t = 0; t < NT; ++t)
-            put_group(W[0], hidden_widths[0], in_features0, t, [&](int h, int j) {
-                const int d = sp::kidx(0, h, j);
-                return s == 0 ? (d < D ? x_col0 + d : -1) : (d < C ? c_col0 + d : -1);
-            });
-    group = sp::groups_l1(NT, k.k1s);
-    // hidden -> hidden, k-major: pair p, tile t, k-steps 2p and 2p+1
+    // layer 1: ONE k-step -- features 0..15 the state dimensions, 16..31 the conditional inputs
+    for (int rt = 0; rt < sp::kRowTiles; ++rt)
+        put_group(W[0], hidden_widths[0], in_features0, rt, [&](int q, int j) {
+            const int f = sp::kidx(0, q, j);
+            return f < 16 ? (f < D ? x_col0 + f : -1) : (f - 16 < C ? c_col0 + f - 16 : -1);
+        });
+    // hidden -> hidden, k-major: k-step s, row tile rt
     for (int l = 1; l < NH; ++l) {
         const int win = hidden_widths[l - 1], wout = hidden_widths[l];
-        for (int p = 0; p < NT; ++p)
-            for (int t = 0; t < NT; ++t)
-                for (int u = 0; u < 2; ++u)
-                    put_group(W[l], wout, win, t, [&](int h, int j) {
-                        const int kk = sp::kidx(2 * p + u, h, j);
-                        return kk < win ? kk : -1;
-                    });
-        group = sp::groups_l1(NT, k.k1s) + (size_t)l * sp::groups_hid(NT);
-        float* bo = out + sp::stream_words(NT, k.k1s, NH) + (size_t)(l - 1) * H;
+        for (int s = 0; s < sp::kKSteps; ++s)
+            for (int rt = 0; rt < sp::kRowTiles; ++rt)
+                put_group(W[l], wout, win, rt, [&](int q, int j) {
+                    const int kk = sp::kidx(s, q, j);
+                    return kk < win ? kk : -1;
+                });
+        float* bo = out + sp::stream_words(NH) + (size_t)(l - 1) * H;
         for (int row = 0; row < wout; ++row) bo[row] = b[l][row];
     }
-    // output layer: one row tile, all k-steps
+    // output layer: one row tile (the state's dimensions), all k-steps
     {
         const int win = hidden_widths[NH - 1];
-        for (int s = 0; s < 2 * NT; ++s)
-            put_group(W[NH], D, win, 0, [&](int h, int j) {
-                const int kk = sp::kidx(s, h, j);
+        for (int s = 0; s < sp::kKSteps; ++s)
+            put_group(W[NH], D, win, 0, [&](int q, int j) {
+                const int kk = sp::kidx(s, q, j);
                 return kk < win ? kk : -1;
             });
-        float* bo = out + sp::stream_words(NT, k.k1s, NH) + (size_t)(NH - 1) * H;
+        float* bo = out + sp::stream_words(NH) + (size_t)(NH - 1) * H;
         for (int row = 0; row < D; ++row) bo[row] = b[NH][row];
     }
-    return FF_OK;
+    return group == (size_t)sp::granules_per_eval(NH) * sp::kGranuleGroups ? FF_OK : FF_ERR_BADARG;
 }
 
 extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
@@ -359,7 +353,7 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.n_tangent = k.tangents ? 1 : 0;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
-    ka.wpack_floats = (int)ff::split::total_words(k.nt, k.k1s, k.n_hidden);
+    ka.wpack_floats = (int)ff::split::total_words(k.n_hidden);
     const long long spw = k.tangents ? 64 : 128;
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;

@@ -5,33 +5,39 @@
 // arithmetic (FF_PREC_BF16X3, opt-in): every fp32 operand of a Linear layer is cut into three bf16 parts
 //     v = hi + mid + lo      hi = top 16 bits of v, mid = top 16 bits of (v - hi), lo = top 16 bits of the rest
 // (24 significand bits in all: exact for the weights, which are split on the host), and a product is the sum of the six
-// v_mfma_f32_32x32x16_bf16 whose parts' magnitudes reach 2^-16 of the full product,
+// bf16 MFMAs whose parts' magnitudes reach 2^-16 of the full product,
 //     w.x ~= wh.xh + wh.xm + wm.xh + wh.xl + wm.xm + wl.xh          (dropped terms: <= 2^-24 relative)
 // accumulated in fp32 by the MFMA.  Error of a layer ~1e-7 relative to sum |w||x| -- what an fp32 dot product has --
-// at 16/6 = 2.7x the MFMA rate of v_mfma_f32_32x32x2_f32.
+// at 16/6 = 2.7x the MFMA rate of the f32 MFMAs.
 //
-// Mapping.  A wavefront owns 32 MFMA columns (32 samples; in Hutchinson mode 16 samples x (value, tangent)), a
-// workgroup is 4 wavefronts, one per SIMD (the kernel needs ~400 of the 512 registers).  Features sit on MFMA rows:
-// register i of an accumulator tile holds row (i & 3) + 8 (i >> 2) + 4 h on lane half h = lane >> 5, and the eight
-// registers 8u .. 8u+7 of a tile are, element for element, the k-slice the B operand of k-step 2 tile + u wants on that
-// lane half -- so after SiLU and the split an accumulator tile IS two k-steps of the next layer's B fragments and
-// activations never leave registers.  (The weights are packed on the host in the matching k order, kidx() below.)
+// MFMA shape: v_mfma_f32_16x16x32_bf16 (16 cycles).  The 32x32x16 form does the same FLOPs per cycle, but this
+// kernel is power-limited and the chip holds a markedly higher clock on the 16x16 form (measured in this kernel by
+// swapping the instruction: 2.27 vs 1.80 GHz; MI355X_MICROARCH.md, DVFS give-back item 7).
 //
-// Loop order: k-major.  A layer keeps ALL its NT = H/32 accumulator tiles live (NT x 16 registers) and walks the
-// k-steps in pairs: pair p needs exactly the previous layer's tile p, whose SiLU + split (VALU, ~55 instructions per
-// register) is issued one pair ahead, in the shadow of the 12 NT MFMAs of the pair before (a bf16 MFMA holds the
-// vector issue port for a quarter of its duration).  Two sets of NT tiles ping-pong between consecutive layers; a tile
-// is refilled with the bias of its next use (from LDS) as soon as it has been consumed, so the MFMA chain adds the bias.
+// Mapping.  A wavefront owns 32 MFMA columns = two column blocks of 16 (32 samples; in Hutchinson mode 16 samples x
+// (value, tangent)); a workgroup is 4 wavefronts, one per SIMD (the kernel needs ~480 of the 512 registers).  Lane l
+// of a 16x16 accumulator tile holds column l & 15 and rows 4 (l >> 4) + i in its 4 registers; the B operand of the
+// MFMA wants, on the same lane, 8 consecutive k slots 8 (l >> 4) + j.  So the accumulator tiles of TWO consecutive
+// 16-row tiles (2s, 2s+1) are, register for register, the B operand of k-step s of the next layer if the weights'
+// k slots are laid out as kidx() below says: after SiLU and the split, activations never leave registers.
+//
+// Loop order: k-major.  A layer keeps ALL its 16 row tiles x 2 column blocks live (128 registers) and walks the
+// k-steps (32 features each); k-step s needs exactly row tiles 2s, 2s+1 of the previous layer, whose SiLU + split
+// (~12 VALU instructions per element, cut into four stages issued one group apart) is done one k-step ahead, in the
+// shadow of that k-step's 192 MFMAs.  Two sets of tiles ping-pong between consecutive layers; a tile is refilled with
+// the bias of its next use (from LDS) as soon as it has been consumed, so the MFMA chain adds the bias.
 //
 // Weights: every wavefront needs every fragment, so they are staged through LDS and shared by the workgroup.  The
 // fragments of one evaluation form a linear stream of 24 KiB granules (8 groups x [hi, mid, lo] x 1 KiB; one group =
-// one (row tile, k-step) = 6 MFMAs) in consumption order, periodic over evaluations.  Three LDS buffers: at the start
-// of granule g each wavefront starts the LDS-DMA (global_load_lds_dwordx4, no registers) of its quarter of granule
-// g+2; before the last group of granule g a counted wait (vmcnt(6): all but the DMAs just issued) and ONE barrier
-// publish granule g+1 and retire granule g-1's buffer.  The per-evaluation first-layer bias c1_e travels the same way.
+// one (16-row tile, k-step) = 12 MFMAs: six products x two column blocks) in consumption order, periodic over
+// evaluations.  Three LDS buffers: at the start of granule g each wavefront starts the LDS-DMA
+// (global_load_lds_dwordx4, no registers) of its quarter of granule g+2; before the last group of granule g a counted
+// wait (vmcnt(6): all but the DMAs just issued) and ONE barrier publish granule g+1 and retire granule g-1's buffer.
+// The per-evaluation first-layer bias c1_e travels the same way.
 //
-// Scope of this family: width 256 (NT = 8), dim <= 16, cond <= 16, SiLU, FF_MODE_STATE and FF_MODE_HUTCH, any
-// fixed-grid table (<= 7 stage slots, kept in LDS); no noise rows, no adaptive-step outputs, no Jacobian output.
+// Scope of this family: width 256, dim <= 16, cond <= 16 (state and conditional inputs share the first layer's single
+// k-step), SiLU, 1-6 hidden layers, FF_MODE_STATE and FF_MODE_HUTCH, any fixed-grid table (<= 7 stage slots, kept in
+// LDS with the state); no noise rows, no adaptive-step outputs, no Jacobian output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,7 +49,6 @@
 namespace ff {
 namespace split {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -59,28 +64,20 @@ __device__ __forceinline__ void sfor(F&& f)
     sfor_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c)
+__device__ __forceinline__ f32x4 mm(u32x4 a, u32x4 b, f32x4 c)
 {
-#ifdef FF_SPLIT_MFMA16          // timing experiment only: the same FLOPs as two 16x16x32 MFMAs (wrong results)
-    f32x4 lo = f32x4{c[0], c[1], c[2], c[3]}, hi = f32x4{c[4], c[5], c[6], c[7]};
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), lo, 0, 0, 0);
-    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), hi, 0, 0, 0);
-    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
-    c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// one group: the six products of (w_hi, w_mid, w_lo) x (x_hi, x_mid, x_lo) that matter
-__device__ __forceinline__ void group6(f32x16& acc, const u32x4 (&w)[3], const u32x4 (&b)[3])
+// one group: the six products of (w_hi, w_mid, w_lo) x (x_hi, x_mid, x_lo) that matter, for both column blocks
+// (interleaved: consecutive MFMAs never depend on each other)
+__device__ __forceinline__ void group12(f32x4 (&acc)[2], const u32x4 (&w)[3], const u32x4 (&b)[2][3])
 {
-    acc = mm(w[0], b[0], acc);
-    acc = mm(w[0], b[1], acc);
-    acc = mm(w[1], b[0], acc);
-    acc = mm(w[0], b[2], acc);
-    acc = mm(w[1], b[1], acc);
-    acc = mm(w[2], b[0], acc);
+    acc[0] = mm(w[0], b[0][0], acc[0]); acc[1] = mm(w[0], b[1][0], acc[1]);
+    acc[0] = mm(w[0], b[0][1], acc[0]); acc[1] = mm(w[0], b[1][1], acc[1]);
+    acc[0] = mm(w[1], b[0][0], acc[0]); acc[1] = mm(w[1], b[1][0], acc[1]);
+    acc[0] = mm(w[0], b[0][2], acc[0]); acc[1] = mm(w[0], b[1][2], acc[1]);
+    acc[0] = mm(w[1], b[0][1], acc[0]); acc[1] = mm(w[1], b[1][1], acc[1]);
+    acc[0] = mm(w[2], b[0][0], acc[0]); acc[1] = mm(w[2], b[1][0], acc[1]);
 }
 // top halves of (a, b) -> one register of two bf16 (a in the low half): truncation split
 __device__ __forceinline__ unsigned pack_hi(float a, float b)
@@ -102,42 +99,23 @@ __device__ __forceinline__ float from_value_lane(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));
 }
-// hidden activation of one pre-activation.  Value columns: SiLU(a).  Tangent columns (forward-mode derivative through
-// the same weights): a' * SiLU'(a of the sample's value column),  SiLU'(a) = s + a s (1 - s),  s = sigmoid(a).
-template <bool TANGENTS>
-__device__ __forceinline__ float act1(float a, bool is_tangent)
-{
-#ifdef FF_SPLIT_NOACT           // timing experiment only: identity activation (wrong results)
-    return a;
-#endif
-    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896340736f));
-    const float h = a * s;
-    if constexpr (!TANGENTS) return h;
-    const float d = __builtin_fmaf(h, 1.0f - s, s);
-    const float dv = from_value_lane(d);
-    return is_tangent ? a * dv : h;
-}
-// unit U (0..7) of a tile: registers 2U, 2U+1 -> word U & 3 of the fragments of k-step U >> 2
-template <bool TANGENTS, int U>
-__device__ __forceinline__ void act_unit(const f32x16& acc, u32x4 (&bf)[2][3], bool is_tangent)
-{
-    split2(act1<TANGENTS>(acc[2 * U], is_tangent), act1<TANGENTS>(acc[2 * U + 1], is_tangent), bf[U >> 2], U & 3);
-}
 
-// The same unit cut into four stages that are issued one GROUP (6 MFMAs, ~190 cycles) apart, so that no instruction
-// waits on a transcendental issued just before it: the wavefront issues in order, and a VALU instruction stalled on
-// its operand holds the next MFMA behind it.  Between stages a unit lives in four registers.
+// Activation + split of one UNIT = two pre-activations -> one word of the three fragments, cut into four stages that
+// are issued one GROUP (12 MFMAs, ~190 cycles) apart, so that no instruction waits on a transcendental issued just
+// before it: the wavefront issues in order, and a VALU instruction stalled on its operand holds the next MFMA behind
+// it.  Between stages a unit lives in four registers.  Value columns: SiLU(a).  Tangent columns (forward-mode
+// derivative through the same weights): a' * SiLU'(a of the sample's value column), SiLU'(a) = s + a s (1 - s).
 struct UnitState {
     float a0, a1, t0, t1;
 };
-template <bool TANGENTS, int U, int STAGE>
-__device__ __forceinline__ void act_unit_stage(const f32x16& acc, UnitState& u, u32x4 (&bf)[2][3], bool is_tangent)
+template <bool TANGENTS, int STAGE>
+__device__ __forceinline__ void unit_stage(float pre0, float pre1, UnitState& u, u32x4 (&frag)[3], int word, bool is_tangent)
 {
     constexpr float NLOG2E = -1.44269504088896340736f;
     if constexpr (STAGE == 0) {            // pre-activations out of the accumulator; exp(-a)
-        u.a0 = acc[2 * U];
-        u.a1 = acc[2 * U + 1];
-#ifdef FF_SPLIT_NOACT
+        u.a0 = pre0;
+        u.a1 = pre1;
+#ifdef FF_SPLIT_NOACT           // timing experiment only: identity activation (wrong results)
         u.t0 = u.a0; u.t1 = u.a1;
 #else
         u.t0 = __builtin_amdgcn_exp2f(u.a0 * NLOG2E);
@@ -148,7 +126,7 @@ __device__ __forceinline__ void act_unit_stage(const f32x16& acc, UnitState& u, 
         u.t0 = __builtin_amdgcn_rcpf(1.0f + u.t0);
         u.t1 = __builtin_amdgcn_rcpf(1.0f + u.t1);
 #endif
-    } else if constexpr (STAGE == 2) {     // activation value (tangent columns: a' * SiLU'(a of the value column)); first residual
+    } else if constexpr (STAGE == 2) {     // activation value; first residual
 #ifdef FF_SPLIT_NOACT
         const float h0 = u.a0, h1 = u.a1;
 #else
@@ -168,30 +146,19 @@ __device__ __forceinline__ void act_unit_stage(const f32x16& acc, UnitState& u, 
 #endif
     } else {                               // second residual and the three packed words
 #ifdef FF_SPLIT_NOSPLIT
-        bf[U >> 2][0][U & 3] = bf[U >> 2][1][U & 3] = bf[U >> 2][2][U & 3] = pack_hi(u.a0, u.a1);
+        frag[0][word] = frag[1][word] = frag[2][word] = pack_hi(u.a0, u.a1);
 #else
         const float l0 = u.t0 - top(u.t0), l1 = u.t1 - top(u.t1);
-        bf[U >> 2][0][U & 3] = pack_hi(u.a0, u.a1);
-        bf[U >> 2][1][U & 3] = pack_hi(u.t0, u.t1);
-        bf[U >> 2][2][U & 3] = pack_hi(l0, l1);
+        frag[0][word] = pack_hi(u.a0, u.a1);
+        frag[1][word] = pack_hi(u.t0, u.t1);
+        frag[2][word] = pack_hi(l0, l1);
 #endif
     }
 }
-// Schedule of a tile's 8 units over the groups of a span: unit u starts at group `start(u)`, stage k runs at group
-// start(u) + k.  kind 0: a whole k-step pair of a hidden layer (16 groups: starts 0,1,3,4,6,7,9,10);
-// kind 1: the 14 groups after a tile's own completion (starts 2 + u);  kind 2: the 7 groups after layer 1's tile 0
-// (two units per group: starts 1 + u / 2).
-FF_HD constexpr int unit_start(int kind, int u) { return kind == 0 ? (3 * u) / 2 : (kind == 1 ? 2 + u : 1 + u / 2); }
-// run whatever stages of the tile's units fall on group `G` of the span
-template <bool TANGENTS, int KIND, int G>
-__device__ __forceinline__ void act_stages_at(const f32x16& acc, UnitState (&us)[8], u32x4 (&bf)[2][3], bool is_tangent)
-{
-    sfor<8>([&](auto uu) {
-        constexpr int U = decltype(uu)::value;
-        constexpr int k = G - unit_start(KIND, U);
-        if constexpr (k >= 0 && k < 4) act_unit_stage<TANGENTS, U, k>(acc, us[U], bf, is_tangent);
-    });
-}
+// Schedule of the 8 units of a k-step's operands over the groups of a span: unit u starts at group start(u), stage k
+// runs at group start(u) + k.  kind 0: the 16 groups of the k-step before (starts 0,1,3,4,6,7,9,10); kind 1: the 14
+// groups after row tiles 0 and 1 of a layer's own output are complete (starts 2 + u).
+FF_HD constexpr int unit_start(int kind, int u) { return kind == 0 ? (3 * u) / 2 : 2 + u; }
 
 // LDS-DMA of one fragment: 64 lanes x 16 bytes from `g` (wave-uniform) + lane * 16 to LDS byte `lds_byte` + lane * 16.
 // Inline asm on purpose: as a builtin the DMA makes hipcc spill, and every spill reload then queues behind it.
@@ -201,98 +168,93 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 }
 
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
-// straight-line body and the 2 x NT accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle
-// all 256 accumulator registers at every control-flow join).
-template <int NT, int K1S, int NH, bool TANGENTS>
+// straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
+// accumulator registers at every control-flow join).
+template <int NH, bool TANGENTS>
 __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
-    static_assert(NT == 8, "the granule schedule below is written for width 256 (8 row tiles)");
-    constexpr int H = 32 * NT;
+    constexpr int NR = kRowTiles;                      // 16 row tiles of 16 rows: width 256
+    constexpr int NS = kKSteps;                        // 8 k-steps of 32 features
+    constexpr int H = 16 * NR;
     constexpr int GB = kGranuleBytes;                  // 24 KiB
-    constexpr int R = 8;                               // state registers per lane (16 dimensions over two lane halves)
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hf = lane >> 5;                          // lane half = k half of the fragments
-    const int col = lane & 31;
+    const int qd = lane >> 4;                          // quad: rows 4 qd .. 4 qd + 3 of a tile, k slots 8 qd .. 8 qd + 7
+    const int col = lane & 15;                         // column within a column block
     const int lane16 = lane * 16;
     const int D = args.dim, C = args.cond_dim;
     const LdsMap M = lds_map(H, NH);
 
-    // ---- column roles ---------------------------------------------------------------------------------------------
+    // ---- column roles: this lane serves one column of each of the two column blocks ---------------------------------
     const long long wave = (long long)blockIdx.x * 4 + wv;
-    long long sample;
-    bool is_tangent = false, col_live = true;
-    if constexpr (TANGENTS) {
-        sample = wave * 16 + (col >> 1);
-        is_tangent = (col & 1) != 0;
-    } else {
-        sample = wave * 32 + col;
-    }
-    if (sample >= args.batch) { sample = args.batch - 1; col_live = false; }
-
-    // ---- state / probe / conditional ------------------------------------------------------------------------------
-    // register j holds dimension kidx(0, hf, j) = 8 (j >> 2) + 4 hf + (j & 3)
-    float x[R];
+    long long sample[2];
+    bool live[2];
+    bool is_tangent = false;
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int d = kidx(0, hf, j);
-        float v = 0.f;
-        if (d < D) {
-            if (!is_tangent) {
-                v = args.x_in[sample * D + d];
-                if (args.in_shift) v = v - args.in_shift[d];
-                if (args.in_scale) v = v / args.in_scale[d];
-            } else {
-                v = args.probe[sample * D + d];
+    for (int cb = 0; cb < 2; ++cb) {
+        if constexpr (TANGENTS) {
+            sample[cb] = wave * 16 + cb * 8 + (col >> 1);
+            is_tangent = (col & 1) != 0;
+        } else {
+            sample[cb] = wave * 32 + cb * 16 + col;
+        }
+        live[cb] = sample[cb] < args.batch;
+        if (!live[cb]) sample[cb] = args.batch - 1;
+    }
+
+    // ---- state / probe / conditional: register i of column block cb holds dimension 4 qd + i -------------------------
+    f32x4* const ks = (f32x4*)(lds + M.slots) + threadIdx.x;          // slot s, column block cb: ks[(s * 2 + cb) * 256]
+    float ee[2] = {0.f, 0.f};                          // tangent lanes: e.e restricted to this lane's dimensions
+    u32x4 yf[2][3];                                    // B fragments of the first layer: words 0,1 = state, 2,3 = conditional
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, cv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = 4 * qd + i;
+            if (d < D) {
+                if (!is_tangent) {
+                    float v = args.x_in[sample[cb] * D + d];
+                    if (args.in_shift) v = v - args.in_shift[d];
+                    if (args.in_scale) v = v / args.in_scale[d];
+                    xv[i] = v;
+                } else {
+                    xv[i] = args.probe[sample[cb] * D + d];
+                }
             }
+            if (d < C && !is_tangent) cv[i] = args.cond[sample[cb] * C + d];
         }
-        x[j] = v;
-    }
-    u32x4 yf[K1S][3];                                  // B fragments of the first layer: k-step 0 = state, 1 = conditional
-    if constexpr (K1S > 1) {
-        float cnd[8];
+        if constexpr (TANGENTS) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = kidx(0, hf, j);
-            cnd[j] = (d < C && !is_tangent) ? args.cond[sample * C + d] : 0.f;
+            for (int i = 0; i < 4; ++i) ee[cb] = __builtin_fmaf(xv[i], xv[i], ee[cb]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split2(cnd[2 * j], cnd[2 * j + 1], yf[1], j);
+        // the state x lives in LDS (slot kSlots + 1; slot kSlots parks the stage input y): it is touched twice per
+        // evaluation, and 8 more live registers would spill inside the loop
+        ks[((kSlots + 1) * 2 + cb) * 256] = xv;
+        split2(cv[0], cv[1], yf[cb], 2);
+        split2(cv[2], cv[3], yf[cb], 3);
     }
-    float ee = 0.f;                                    // tangent lanes: e.e restricted to this lane's dimensions
-    if constexpr (TANGENTS) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) ee = __builtin_fmaf(x[j], x[j], ee);
-    }
-
-    // ---- LDS set-up: stage slots, zero page, static biases --------------------------------------------------------
-    f32x4* const ks = (f32x4*)(lds + M.slots) + threadIdx.x;          // slot s, quad j4: ks[(s * 2 + j4) * 256]
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
-        for (int j4 = 0; j4 < 2; ++j4) ks[(s * 2 + j4) * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the state x lives in LDS as well (slot kSlots + 1; slot kSlots parks the stage input y): it is touched twice per
-    // evaluation, and 8 more live registers would spill inside the loop
-#pragma unroll
-    for (int j4 = 0; j4 < 2; ++j4)
-        ks[((kSlots + 1) * 2 + j4) * 256] = f32x4{x[4 * j4], x[4 * j4 + 1], x[4 * j4 + 2], x[4 * j4 + 3]};
+        for (int cb = 0; cb < 2; ++cb) ks[(s * 2 + cb) * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
-        const float* bsrc = args.wpack + (size_t)stream_words(NT, K1S, NH);
-        const int nb = (NH - 1) * H + 32;
+        const float* bsrc = args.wpack + (size_t)stream_words(NH);
+        const int nb = (NH - 1) * H + 16;
         for (int i = threadIdx.x; i < nb; i += 256) ((float*)(lds + M.hbias))[i] = bsrc[i];
     }
-    float kl[kSlots];
+    float kl[kSlots][2];
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) kl[s] = 0.f;
-    float lp = 0.f;
+    for (int s = 0; s < kSlots; ++s) kl[s][0] = kl[s][1] = 0.f;
+    float lp[2] = {0.f, 0.f};
 
     // ---- weight pipeline state (all wave-uniform) -----------------------------------------------------------------
     const unsigned char* const wbase = (const unsigned char*)args.wpack;
-    const long long wbytes = (long long)granules_per_eval(NT, K1S, NH) * GB;
+    const long long wbytes = (long long)granules_per_eval(NH) * GB;
     long long dpos = 0;                                // byte position in the stream of the NEXT granule to fetch
     unsigned rbuf = 0;                                 // LDS byte offset of the buffer the current granule is read from
     const int my_frag = wv * 6 * 1024;                 // this wavefront's quarter of a granule
@@ -307,8 +269,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         dpos += GB;
         if (dpos >= wbytes) dpos = 0;
     };
-    auto fetch_c1 = [&](int e) __attribute__((always_inline)) {                       // c1 of evaluation e -> its LDS buffer (every wavefront issues the
-        const int ee_ = e < args.n_evals ? e : 0;      // same 1 KiB copy: equal VMEM counts keep the counted waits uniform)
+    auto fetch_c1 = [&](int e) __attribute__((always_inline)) {      // c1 of evaluation e -> its LDS buffer (every wavefront issues
+        const int ee_ = e < args.n_evals ? e : 0;                      // the same 1 KiB copy: equal VMEM counts keep the counted waits uniform)
         dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32), lane16);
     };
     fetch_c1(0);
@@ -317,25 +279,18 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // bias tile t of the vector at LDS byte `base` (tangent lanes read the zero page): accumulator register order
-    const int zsel = M.zero + hf * 16;
-    auto bias_tile = [&](int base, int t) __attribute__((always_inline)) {
-        const int a = (TANGENTS && is_tangent) ? zsel : base + hf * 16;
-        f32x16 r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *(const f32x4*)(lds + a + (32 * t + 8 * g) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[4 * g + i] = v[i];
-        }
-        return r;
+    // bias of row tile rt of the vector at LDS byte `base` (tangent lanes read the zero page): accumulator register order
+    const int zsel = M.zero + qd * 16;
+    auto bias_tile = [&](int base, int rt) __attribute__((always_inline)) {
+        const int a = (TANGENTS && is_tangent) ? zsel : base + qd * 16;
+        return *(const f32x4*)(lds + a + 64 * rt);
     };
 
-    f32x16 A[NT], B[NT];
+    f32x4 A[NR][2], B[NR][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        A[t] = bias_tile(M.c1, t);
-        B[t] = bias_tile(M.hbias, t);                  // (unused when there is a single hidden layer)
+    for (int rt = 0; rt < NR; ++rt) {
+        A[rt][0] = A[rt][1] = bias_tile(M.c1, rt);
+        B[rt][0] = B[rt][1] = bias_tile(M.hbias, rt);  // (unused when there is a single hidden layer)
     }
 
     // weight fragments of the current group (w) and the next one (wn), read from LDS one group ahead
@@ -387,39 +342,62 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);
     };
 
-    u32x4 bf[2][2][3];                                 // B fragments of the k-step pair in use / in preparation
+    u32x4 bf[2][2][3];                                 // B fragments [k-step parity][column block][part] in use / in preparation
     UnitState us[8];                                   // activation units in flight (four stages, one group apart)
 
-    // A hidden -> hidden layer (reads P, writes C) or, with OUT, the output layer (reads P, writes O[0]).
+    // Stages of the units that turn row tiles (2 sn, 2 sn + 1) of `T` into the fragments of k-step sn, falling on group
+    // G of a span (schedule `KIND`).  Unit u: column block u >> 2, word u & 3 = registers 2 (u & 1), 2 (u & 1) + 1 of row
+    // tile 2 sn + ((u >> 1) & 1).
+    auto act_at = [&](auto kind, auto gg, auto snn, f32x4 (&T)[NR][2], u32x4 (&dst)[2][3]) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind)::value, G = decltype(gg)::value, sn = decltype(snn)::value;
+        sfor<8>([&](auto uu) {
+            constexpr int U = decltype(uu)::value;
+            constexpr int k = G - unit_start(KIND, U);
+            if constexpr (k >= 0 && k < 4) {
+                constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
+                unit_stage<TANGENTS, k>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
+            }
+        });
+    };
+
+    // A hidden -> hidden layer (reads P, writes Cc) or, with OUT, the output layer (reads P, writes O).
     // `refill` = LDS byte address of the bias vector the tiles of P are refilled with once consumed (their next use).
-    auto layer = [&](auto is_out, f32x16 (&P)[NT], f32x16 (&Cc)[NT], f32x16& O, int refill) __attribute__((always_inline)) {
+    auto layer = [&](auto is_out, f32x4 (&P)[NR][2], f32x4 (&Cc)[NR][2], f32x4 (&O)[2], int refill) __attribute__((always_inline)) {
         constexpr bool OUT = decltype(is_out)::value;
-        P[0] = bias_tile(refill, 0);                   // tile 0 was consumed at the end of the layer before
-        sfor<NT>([&](auto pp) {
-            constexpr int p = decltype(pp)::value;
-            constexpr int NTILE = OUT ? 1 : NT;
+        P[0][0] = P[0][1] = bias_tile(refill, 0);      // row tiles 0, 1 were consumed at the end of the layer before
+        P[1][0] = P[1][1] = bias_tile(refill, 1);
+        sfor<NS>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            constexpr int NTILE = OUT ? 1 : NR;
             sfor<NTILE>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                sfor<2>([&](auto ss) {
-                    constexpr int s = decltype(ss)::value;
-                    constexpr int q = (p * NTILE + t) * 2 + s;
-                    pre(std::integral_constant<int, q % 8>{});
-                    if constexpr (OUT) group6(O, w, bf[p & 1][s]);
-                    else group6(Cc[t], w, bf[p & 1][s]);
-                    // activation stages in the shadow of the MFMAs just issued
-                    if constexpr (OUT) {
-                        if constexpr (p < NT - 1) {    // four whole units per group (the output layer is VALU-bound anyway)
-                            sfor<4>([&](auto uu) { act_unit<TANGENTS, 4 * s + decltype(uu)::value>(P[p + 1], bf[(p + 1) & 1], is_tangent); });
-                        }
-                    } else if constexpr (p < NT - 1) {
-                        act_stages_at<TANGENTS, 0, 2 * t + s>(P[p + 1], us, bf[(p + 1) & 1], is_tangent);
-                    } else {                           // last pair: the first tile of THIS layer's output, complete after group 1
-                        act_stages_at<TANGENTS, 1, 2 * t + s>(Cc[0], us, bf[0], is_tangent);
+                constexpr int rt = decltype(tt)::value;
+                constexpr int q = s * NTILE + rt;
+                pre(std::integral_constant<int, q % 8>{});
+                if constexpr (OUT) group12(O, w, bf[s & 1]);
+                else group12(Cc[rt], w, bf[s & 1]);
+                // activation stages in the shadow of the MFMAs just issued
+                if constexpr (OUT) {
+                    if constexpr (s < NS - 1) {        // one group per k-step: all eight units, whole (the output layer is VALU-bound)
+                        sfor<8>([&](auto uu) {
+                            constexpr int U = decltype(uu)::value;
+                            constexpr int cb = U >> 2, word = U & 3, prt = 2 * (s + 1) + (word >> 1), r0 = 2 * (word & 1);
+                            sfor<4>([&](auto kk) {
+                                unit_stage<TANGENTS, decltype(kk)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
+                                                                         bf[(s + 1) & 1][cb], word, is_tangent);
+                            });
+                        });
                     }
-                    post(std::integral_constant<int, q % 8>{});
-                });
+                } else if constexpr (s < NS - 1) {
+                    act_at(std::integral_constant<int, 0>{}, tt, std::integral_constant<int, s + 1>{}, P, bf[(s + 1) & 1]);
+                } else {                               // last k-step: row tiles 0, 1 of THIS layer's output, complete after groups 0, 1
+                    act_at(std::integral_constant<int, 1>{}, tt, std::integral_constant<int, 0>{}, Cc, bf[0]);
+                }
+                post(std::integral_constant<int, q % 8>{});
             });
-            if constexpr (p < NT - 1) P[p + 1] = bias_tile(refill, p + 1);     // consumed during this pair
+            if constexpr (s < NS - 1) {                // row tiles 2s+2, 2s+3 were consumed during this k-step
+                P[2 * s + 2][0] = P[2 * s + 2][1] = bias_tile(refill, 2 * s + 2);
+                P[2 * s + 3][0] = P[2 * s + 3][1] = bias_tile(refill, 2 * s + 3);
+            }
         });
     };
 
@@ -429,39 +407,28 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         const uint32_t flags = hdr->flags;
         const int slot = hdr->slot;
 
-        // stage input  y = x + sum_s cin[s] k[s]
-        float y[R];
+        // stage input  y = x + sum_s cin[s] k[s]  (parked in LDS slot kSlots for the right-hand side); its fragments
 #pragma unroll
-        for (int j4 = 0; j4 < 2; ++j4) {
-            f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) v += hdr->cin[s] * ks[(s * 2 + j4) * 256];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) y[4 * j4 + i] = v[i];
+            for (int s = 0; s < kSlots; ++s) v += hdr->cin[s] * ks[(s * 2 + cb) * 256];
+            ks[(kSlots * 2 + cb) * 256] = v;
+            split2(v[0], v[1], yf[cb], 0);
+            split2(v[2], v[3], yf[cb], 1);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split2(y[2 * j], y[2 * j + 1], yf[0], j);
-        // y is needed again for the right-hand side, a whole network evaluation later: park it in LDS (slot kSlots)
-#pragma unroll
-        for (int j4 = 0; j4 < 2; ++j4)
-            ks[(kSlots * 2 + j4) * 256] = f32x4{y[4 * j4], y[4 * j4 + 1], y[4 * j4 + 2], y[4 * j4 + 3]};
 
-        // ---- layer 1: [state | conditional] -> H, accumulators A already hold c1_e ---------------------------------
-        sfor<K1S>([&](auto ss) {
-            constexpr int s = decltype(ss)::value;
-            sfor<NT>([&](auto tt) {
-                constexpr int t = decltype(tt)::value;
-                constexpr int q = s * NT + t;
-                pre(std::integral_constant<int, q % 8>{});
+        // ---- layer 1: [state | conditional] (one k-step) -> H, accumulators A already hold c1_e --------------------
+        sfor<NR>([&](auto tt) {
+            constexpr int rt = decltype(tt)::value;
+            pre(std::integral_constant<int, rt % 8>{});
 #ifndef FF_SPLIT_NODMA
-                if constexpr (q == 0) fetch_c1(e + 1);                 // (after the weight DMAs of this granule)
+            if constexpr (rt == 0) fetch_c1(e + 1);                    // (after the weight DMAs of this granule)
 #endif
-                group6(A[t], w, yf[s]);
-                if constexpr (s == K1S - 1) {                           // tile 0 is complete after group 0: its activation rides here
-                    act_stages_at<TANGENTS, 2, t>(A[0], us, bf[0], is_tangent);
-                }
-                post(std::integral_constant<int, q % 8>{});
-            });
+            group12(A[rt], w, yf);
+            // row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
+            act_at(std::integral_constant<int, 1>{}, tt, std::integral_constant<int, 0>{}, A, bf[0]);
+            post(std::integral_constant<int, rt % 8>{});
         });
 
         // ---- hidden -> hidden layers, ping-pong A -> B -> A ..., then the output layer ------------------------------
@@ -473,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if (j + 1 <= NH - 1) return M.hbias + j * H * 4;
             return reads_A ? c1_next : M.hbias;
         };
-        f32x16 O;
+        f32x4 O[2];
         sfor<NH>([&](auto jj) {
             constexpr int j = decltype(jj)::value + 1;                  // layers 1 .. NH-1 hidden -> hidden, NH = output
             constexpr bool reads_A = (j & 1) != 0;
@@ -481,88 +448,78 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 if constexpr (reads_A) layer(std::false_type{}, A, B, O, refill_for(j, true));
                 else layer(std::false_type{}, B, A, O, refill_for(j, false));
             } else {
-                O = bias_tile(M.hbias + (NH - 1) * H * 4, 0);           // output bias (32 rows)
+                O[0] = O[1] = bias_tile(M.hbias + (NH - 1) * H * 4, 0);       // output bias (16 rows)
                 if constexpr (reads_A) layer(std::true_type{}, A, B, O, refill_for(j, true));
                 else layer(std::true_type{}, B, A, O, refill_for(j, false));
             }
         });
 
         // ---- right-hand side and stage bookkeeping ------------------------------------------------------------------
-        float rhs[R];
-        float div = 0.f;
-        if constexpr (TANGENTS) {
-            float dot = 0.f;
 #pragma unroll
-            for (int j4 = 0; j4 < 2; ++j4) {
-                const f32x4 xv = ks[((kSlots + 1) * 2 + j4) * 256];          // tangent lanes: the probe e
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dot = __builtin_fmaf(xv[i], O[4 * j4 + i], dot);
-            }
-            div = is_tangent ? __builtin_fmaf(a_e, ee, b_e * dot) : 0.f;
-        }
-#pragma unroll
-        for (int j4 = 0; j4 < 2; ++j4) {
-            const f32x4 yv = ks[(kSlots * 2 + j4) * 256];
+        for (int cb = 0; cb < 2; ++cb) {
+            const f32x4 yv = ks[(kSlots * 2 + cb) * 256];
+            f32x4 rhs;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = __builtin_fmaf(a_e, yv[i], b_e * O[4 * j4 + i]);
-                rhs[4 * j4 + i] = is_tangent ? 0.f : v;
+                const float v = __builtin_fmaf(a_e, yv[i], b_e * O[cb][i]);
+                rhs[i] = is_tangent ? 0.f : v;
             }
-        }
+            ks[(slot * 2 + cb) * 256] = rhs;
+            if constexpr (TANGENTS) {
+                const f32x4 xv = ks[((kSlots + 1) * 2 + cb) * 256];      // tangent lanes: the probe e
+                float dot = 0.f;
 #pragma unroll
-        for (int j4 = 0; j4 < 2; ++j4)
-            ks[(slot * 2 + j4) * 256] = f32x4{rhs[4 * j4], rhs[4 * j4 + 1], rhs[4 * j4 + 2], rhs[4 * j4 + 3]};
-        if constexpr (TANGENTS) {
+                for (int i = 0; i < 4; ++i) dot = __builtin_fmaf(xv[i], O[cb][i], dot);
+                const float div = is_tangent ? __builtin_fmaf(a_e, ee[cb], b_e * dot) : 0.f;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) kl[s] = (slot == s) ? div : kl[s];
+                for (int s = 0; s < kSlots; ++s) kl[s][cb] = (slot == s) ? div : kl[s][cb];
+            }
         }
         if (flags & 1u) {
 #pragma unroll
-            for (int j4 = 0; j4 < 2; ++j4) {
-                f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
+            for (int cb = 0; cb < 2; ++cb) {
+                f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) v += hdr->cout[s] * ks[(s * 2 + j4) * 256];
-                ks[((kSlots + 1) * 2 + j4) * 256] = v;
-            }
-            if constexpr (TANGENTS) {
+                for (int s = 0; s < kSlots; ++s) v += hdr->cout[s] * ks[(s * 2 + cb) * 256];
+                ks[((kSlots + 1) * 2 + cb) * 256] = v;
+                if constexpr (TANGENTS) {
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) lp = __builtin_fmaf(hdr->cout[s], kl[s], lp);
+                    for (int s = 0; s < kSlots; ++s) lp[cb] = __builtin_fmaf(hdr->cout[s], kl[s][cb], lp[cb]);
+                }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pipeline runs two granules ahead: let it drain
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------
-    const bool writer = col_live && !is_tangent;
-    if constexpr (TANGENTS) {
-        // the sample's divergence = sum over both lane halves of its tangent column (the next lane)
-        float tot = 0.f;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int src = ((g << 5) | ((col + 1) & 31)) * 4;
-            tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp)));
-        }
-        if (writer && hf == 0 && args.dlogp_out) args.dlogp_out[sample] = (args.dlogp_in ? args.dlogp_in[sample] : 0.f) + tot;
-    }
     bool bad = false;
-    float xfin[R];
 #pragma unroll
-    for (int j4 = 0; j4 < 2; ++j4) {
-        const f32x4 v = ks[((kSlots + 1) * 2 + j4) * 256];
+    for (int cb = 0; cb < 2; ++cb) {
+        const bool writer = live[cb] && !is_tangent;
+        if constexpr (TANGENTS) {
+            // the sample's divergence = sum over the four quads of its tangent column (the next lane)
+            float tot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xfin[4 * j4 + i] = v[i];
-    }
-    if (writer) {
+            for (int g = 0; g < 4; ++g) {
+                const int src = ((g << 4) | ((col + 1) & 15)) * 4;
+                tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp[cb])));
+            }
+            if (writer && qd == 0 && args.dlogp_out)
+                args.dlogp_out[sample[cb]] = (args.dlogp_in ? args.dlogp_in[sample[cb]] : 0.f) + tot;
+        }
+        const f32x4 xv = ks[((kSlots + 1) * 2 + cb) * 256];
+        if (writer) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int d = kidx(0, hf, r);
-            if (d < D) {
+            for (int i = 0; i < 4; ++i) {
+                const int d = 4 * qd + i;
+                if (d < D) {
 #pragma clang fp contract(off)      // x * scale + shift as two roundings, like the reference's torch expression
-                float v = xfin[r];
-                bad |= (v != v);
-                if (args.out_scale) v = v * args.out_scale[d];
-                if (args.out_shift) v = v + args.out_shift[d];
-                args.x_out[sample * D + d] = v;
+                    float v = xv[i];
+                    bad |= (v != v);
+                    if (args.out_scale) v = v * args.out_scale[d];
+                    if (args.out_shift) v = v + args.out_shift[d];
+                    args.x_out[sample[cb] * D + d] = v;
+                }
             }
         }
     }

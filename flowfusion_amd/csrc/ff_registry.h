@@ -26,10 +26,8 @@ struct KernelEntry {
 extern const KernelEntry g_kernels[];
 extern const int g_n_kernels;
 
-// split-precision family (FF_PREC_BF16X3, ff_mlp_ode_split.hpp): width 32 * nt, dim <= 16, cond <= 16 * (k1s - 1)
+// split-precision family (FF_PREC_BF16X3, ff_mlp_ode_split.hpp): width <= 256, dim <= 16, cond <= 16
 struct SplitKernelEntry {
-    int nt;         // row tiles = width / 32
-    int k1s;        // k-steps of the first layer: 1 = state only, 2 = state + conditional inputs
     int n_hidden;   // hidden layers (compile-time in this family)
     int tangents;   // 1: Hutchinson-capable instantiation (value / tangent column pairs)
     LaunchFn launch;

@@ -1,17 +1,19 @@
 // ff_split_layout.h -- weight stream and LDS map of the split-precision (FF_PREC_BF16X3) kernels, shared by the
 // host-side packer (ff_api.cpp) and the gfx950 kernel (ff_mlp_ode_split.hpp).
 //
-// MFMA: v_mfma_f32_32x32x16_bf16.  The A operand (weights) of one k-step is a FRAGMENT: 64 lanes x 8 bf16 = 1 KiB,
-// lane l = (row l & 31 of a 32-row tile, k half l >> 5), element j of the lane = input feature kidx(s, l >> 5, j) of
-// k-step s.  kidx is the order in which the registers of an fp32 accumulator tile (register i of lane half h = row
-// (i & 3) + 8 (i >> 2) + 4 h) line up as B operands of the next layer: registers 8u .. 8u+7 of row tile t are k-step
-// 2t + u.  A GROUP = the three fragments [hi, mid, lo] of one (row tile, k-step) = 6 MFMAs; a GRANULE = 8 groups =
-// 24 KiB, the unit of the LDS pipeline.  Stream of one evaluation, in consumption order (NT = H / 32 row tiles):
-//     layer 1          for k-step s < K1S (0: state dimensions, 1: conditional inputs):  for tile t:  group (t, s)
-//     hidden layer l   for pair p < NT:  for tile t < NT:  groups (t, 2p), (t, 2p + 1)               l = 1 .. NH-1
-//     output layer     for k-step s < 2 NT:  group (tile 0, s)
-// every layer padded to whole granules.  Behind the stream: the fp32 biases of the hidden->hidden layers
-// [(NH-1)][H] and of the output layer [32] (the first layer's bias travels in the evaluation table as c1_e).
+// MFMA: v_mfma_f32_16x16x32_bf16.  The A operand (weights) of one (16-row tile, k-step of 32 features) is a FRAGMENT:
+// 64 lanes x 8 bf16 = 1 KiB, lane l = (row l & 15 of the tile, quad q = l >> 4), element j of the lane = input feature
+// kidx(s, q, j) of k-step s.  kidx is the order in which the registers of two fp32 accumulator tiles line up as the B
+// operand of the next layer: a 16x16 accumulator tile keeps rows 4 q + i (i < 4) on quad q, the B operand wants k slots
+// 8 q + j (j < 8) there, so slots j < 4 of k-step s are rows 4 q + j of row tile 2s and slots j >= 4 are rows
+// 4 q + (j - 4) of row tile 2s + 1.  A GROUP = the three fragments [hi, mid, lo] of one (row tile, k-step) = 12 MFMAs
+// (six products x two column blocks of 16 samples); a GRANULE = 8 groups = 24 KiB, the unit of the LDS pipeline.
+// Stream of one evaluation, in consumption order (width 256: 16 row tiles, 8 k-steps):
+//     layer 1          one k-step (features 0..15 = state dimensions, 16..31 = conditional inputs): for row tile rt
+//     hidden layer l   for k-step s < 8:  for row tile rt < 16:  group (rt, s)                       l = 1 .. NH-1
+//     output layer     one row tile (the state's 16 dimensions):  for k-step s < 8:  group (0, s)
+// Behind the stream: the fp32 biases of the hidden->hidden layers [(NH-1)][256] and of the output layer [16] (the
+// first layer's bias travels in the evaluation table as c1_e).
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -20,39 +22,35 @@
 namespace ff {
 namespace split {
 
+constexpr int kRowTiles = 16;         // 16-row tiles of a 256-wide layer
+constexpr int kKSteps = 8;            // 32-feature k-steps of a 256-wide layer
+constexpr int kWidth = 256;
 constexpr int kFragBytes = 1024;
 constexpr int kGroupFrags = 3;
 constexpr int kGranuleGroups = 8;
 constexpr int kGranuleBytes = kFragBytes * kGroupFrags * kGranuleGroups;     // 24 KiB
 constexpr int kBuffers = 3;
 
-// input feature held by element j (0..7) of lane half h in the fragment of k-step s
-FF_HD constexpr int kidx(int s, int h, int j) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+// input feature held by element j (0..7) of quad q in the fragment of k-step s
+FF_HD constexpr int kidx(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
 
-FF_HD constexpr int pad8(int groups) { return (groups + kGranuleGroups - 1) / kGranuleGroups * kGranuleGroups; }
-FF_HD constexpr int groups_l1(int nt, int k1s) { return pad8(nt * k1s); }
-FF_HD constexpr int groups_hid(int nt) { return pad8(2 * nt * nt); }
-FF_HD constexpr int groups_out(int nt) { return pad8(2 * nt); }
-FF_HD constexpr int granules_per_eval(int nt, int k1s, int n_hidden)
+constexpr int kGroupsL1 = kRowTiles;                  // 16
+constexpr int kGroupsHid = kRowTiles * kKSteps;       // 128
+constexpr int kGroupsOut = kKSteps;                   // 8
+FF_HD constexpr int granules_per_eval(int n_hidden)
 {
-    return (groups_l1(nt, k1s) + (n_hidden - 1) * groups_hid(nt) + groups_out(nt)) / kGranuleGroups;
+    return (kGroupsL1 + (n_hidden - 1) * kGroupsHid + kGroupsOut) / kGranuleGroups;
 }
 // 4-byte words of the fragment stream / of the whole packed buffer
-FF_HD constexpr size_t stream_words(int nt, int k1s, int n_hidden)
-{
-    return (size_t)granules_per_eval(nt, k1s, n_hidden) * (kGranuleBytes / 4);
-}
-FF_HD constexpr size_t total_words(int nt, int k1s, int n_hidden)
-{
-    return stream_words(nt, k1s, n_hidden) + (size_t)(n_hidden - 1) * 32 * nt + 32;
-}
+FF_HD constexpr size_t stream_words(int n_hidden) { return (size_t)granules_per_eval(n_hidden) * (kGranuleBytes / 4); }
+FF_HD constexpr size_t total_words(int n_hidden) { return stream_words(n_hidden) + (size_t)(n_hidden - 1) * kWidth + 16; }
 
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
     int wbuf;    // kBuffers x 24 KiB weight granules
     int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (kSlots + 2) x 2 x 256 threads x 16 B
     int c1;      // 2 x H floats: first-layer bias of the current / next evaluation
-    int hbias;   // (NH-1) x H floats + 32: hidden->hidden and output biases
+    int hbias;   // (NH-1) x H floats + 16: hidden->hidden and output biases
     int zero;    // H floats of zeros (what tangent columns read instead of a bias)
     int total;
 };
@@ -64,7 +62,7 @@ FF_HD constexpr LdsMap lds_map(int H, int n_hidden)
     m.c1 = m.slots + (7 + 2) * 2 * 256 * 16;
     m.hbias = m.c1 + 2 * H * 4;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
-    m.zero = m.hbias + nh1 * H * 4 + H * 4;      // (one spare vector: a tile read of the 32-float output bias stays inside)
+    m.zero = m.hbias + nh1 * H * 4 + H * 4;      // (one spare vector: a tile read of the 16-float output bias stays inside)
     m.total = m.zero + H * 4;
     return m;
 }

@@ -24,12 +24,12 @@ STATE_TOL = 2e-5
 LOGP_TOL = 2e-5
 
 
-def _kidx(s, h, j):
-    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+def _kidx(s, q, j):
+    return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3)
 
 
 def _decode_group(words, g):
-    """[32 rows, 16 k-elements as (h, j)] fp32 of group g of the stream: hi + mid + lo."""
+    """[64 lanes, 8 elements] fp32 of group g of the stream: hi + mid + lo (lane = 16 quad + row of the 16-row tile)."""
     frag = words[g * 768:(g + 1) * 768].reshape(3, 64, 4)                       # part, lane, word
     halves = np.stack([frag & 0xFFFF, frag >> 16], axis=-1).reshape(3, 64, 8)   # element j = 2 word + half
     vals = (halves.astype(np.uint32) << 16).view(np.float32)
@@ -43,55 +43,53 @@ def test_plan_and_packer_roundtrip(built_library):
     net = sm._net()
     plan = net.plan(MODE_STATE)
     assert (plan.precision, plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden) == (1, 32, 256, 8, 8, 3)
-    assert _native.kernel_name(plan) == "mlp_ode_split_h256_k2_n3_t0"
-    assert _native.kernel_name(net.plan(MODE_HUTCH)) == "mlp_ode_split_h256_k2_n3_t1"
+    assert _native.kernel_name(plan) == "mlp_ode_split_h256_n3_t0"
+    assert _native.kernel_name(net.plan(MODE_HUTCH)) == "mlp_ode_split_h256_n3_t1"
     assert _native.samples_per_workgroup(plan, MODE_STATE) == 128
     assert _native.samples_per_workgroup(net.plan(MODE_HUTCH), MODE_HUTCH) == 64
     pack = net.wpack("cpu", MODE_STATE)
     assert net.wpack("cpu", MODE_HUTCH) is pack                      # one layout for both instantiations
     words = pack.numpy().view(np.uint32)
-    NT, K1S, NH, H = 8, 2, 3, 256
-    n_gran = (8 * K1S + (NH - 1) * 128 + 16) // 8
-    assert words.size == n_gran * 6144 + (NH - 1) * H + 32
+    NR, NS, NH, H = 16, 8, 3, 256
+    n_gran = (NR + (NH - 1) * NR * NS + NS) // 8
+    assert words.size == n_gran * 6144 + (NH - 1) * H + 16
     Ws = [l.weight.detach().numpy() for l in sm.model.NN]
     bs = [l.bias.detach().numpy() for l in sm.model.NN]
     E = 8                                                            # time-embedding columns of the first layer (sin, cos of 4 frequencies)
     g = 0
-    # layer 1: k-step 0 = state columns, k-step 1 = conditional columns
-    for s in range(K1S):
-        for t in range(NT):
-            got = _decode_group(words, g)
-            g += 1
-            for lane in (0, 17, 31, 32, 63):
-                row, h = 32 * t + (lane & 31), lane >> 5
-                for j in range(8):
-                    d = _kidx(0, h, j)
-                    col = (E + d if d < 11 else None) if s == 0 else (E + 11 + d if d < 5 else None)
-                    exp = Ws[0][row, col] if (row < 200 and col is not None) else 0.0
-                    assert got[lane, j] == np.float32(exp)
+    # layer 1: one k-step, features 0..15 = state columns, 16..31 = conditional columns
+    for rt in range(NR):
+        got = _decode_group(words, g)
+        g += 1
+        for lane in (0, 15, 16, 37, 63):
+            row, q = 16 * rt + (lane & 15), lane >> 4
+            for j in range(8):
+                f = _kidx(0, q, j)
+                col = (E + f if f < 11 else None) if f < 16 else (E + 11 + f - 16 if f - 16 < 5 else None)
+                exp = Ws[0][row, col] if (row < 200 and col is not None) else 0.0
+                assert got[lane, j] == np.float32(exp)
     # hidden -> hidden layers, k-major: exact reconstruction of the whole (zero-padded) matrix
     widths = [200, 256, 77]
     for l in range(1, NH):
         rec = np.zeros((H, H), np.float32)
-        for p in range(NT):
-            for t in range(NT):
-                for u in range(2):
-                    got = _decode_group(words, g)
-                    g += 1
-                    for lane in range(64):
-                        for j in range(8):
-                            rec[32 * t + (lane & 31), _kidx(2 * p + u, lane >> 5, j)] = got[lane, j]
+        for s_ in range(NS):
+            for rt in range(NR):
+                got = _decode_group(words, g)
+                g += 1
+                for lane in range(64):
+                    for j in range(8):
+                        rec[16 * rt + (lane & 15), _kidx(s_, lane >> 4, j)] = got[lane, j]
         exp = np.zeros((H, H), np.float32)
         exp[:widths[l], :widths[l - 1]] = Ws[l]
         assert np.array_equal(rec, exp)                              # hi + mid + lo == the fp32 weight, bit for bit
-    rec = np.zeros((32, H), np.float32)
-    for s in range(2 * NT):
+    rec = np.zeros((16, H), np.float32)
+    for s_ in range(NS):
         got = _decode_group(words, g)
         g += 1
         for lane in range(64):
             for j in range(8):
-                rec[lane & 31, _kidx(s, lane >> 5, j)] = got[lane, j]
-    exp = np.zeros((32, H), np.float32)
+                rec[lane & 15, _kidx(s_, lane >> 4, j)] = got[lane, j]
+    exp = np.zeros((16, H), np.float32)
     exp[:11, :77] = Ws[NH]
     assert np.array_equal(rec, exp) and g == n_gran * 8
     tail = pack.numpy()[n_gran * 6144:]
