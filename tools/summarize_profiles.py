@@ -12,6 +12,7 @@
 """
 import csv
 import json
+import re
 import subprocess
 import sys
 from pathlib import Path
@@ -101,9 +102,10 @@ def main(src: Path, dst: Path):
     }
     (dst / "pmc_summary.json").write_text(json.dumps(summary, indent=1))
     head = bench["roofline"]["kernel"]                      # e.g. mlp_ode_m16_h256_d4_c0_t0_w2
-    tag = "<16, 256, 4, 0, false, 2, 8, false>"
+    # the headline instance: 16-column tile, width 256, state only, two wavefronts per SIMD, ring 8, SiLU, not cooperative
+    tag = re.compile(r"mlp_ode_kernel<16, 256, 4, 0, false, 2, 8, (0, )?false(, false)?>")
     for name, e in kernels.items():
-        if tag in name and "hbm_bytes_per_launch" in e:
+        if tag.search(name) and "hbm_bytes_per_launch" in e:
             (dst.parent / "hbm_traffic.json").write_text(json.dumps(
                 {"bytes_per_launch": e["hbm_bytes_per_launch"], "source": f"{dst}/pmc_summary.json", "kernel": name,
                  "batch": bench["config"]["batch_per_gpu"], "commit": _head_commit(), "bench_kernel": head}, indent=1))
