@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void stage_combine_kernel(const CombineArgs a)
 // ---- scaled RMS norms of an adaptive step (one launch, one small read-back) ----------------------------------------
 // out[i] = sqrt(mean_k (((num_i[k] - sub_i[k]) / (atol + rtol * max(|s0_i[k]|, |s1_i[k]|)))^2)),  out[n_terms] = 1 if
 // `check` holds a non-finite value else 0.  Deterministic: every block reduces its grid-stride share in a fixed tree,
-// writes one partial per term to the workspace, and the block that arrives last adds the partials up in block order
+// writes one partial per term to the workspace, and the block that arrives last adds the partials up in a fixed order
 // (double accumulation) -- no floating-point atomics, so equal inputs give equal norms and the accept / reject
 // decisions of two runs agree.  Workspace: 1 counter word (left at zero) + kNormBlocks x (FF_NORM_TERMS + 1) doubles.
-constexpr int kNormBlocks = 256;
+constexpr int kNormBlocks = 2048;      // 8 workgroups per CU: enough 16-byte loads in flight to stream at the HBM rate
 
 struct NormArgs {
     const float* num[FF_NORM_TERMS];
@@ -97,8 +97,10 @@ struct NormArgs {
     const float* s0[FF_NORM_TERMS];
     const float* s1[FF_NORM_TERMS];
     long long n[FF_NORM_TERMS];
+    int vec_ok[FF_NORM_TERMS];   // every array of the term 16-byte aligned: the body runs on float4
     const float* check;
     long long n_check;
+    int check_vec_ok;
     int n_terms;
     float atol, rtol;
     float* out;
@@ -121,30 +123,47 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
     return t;              // valid on thread 0
 }
 
+__device__ __forceinline__ double scaled_sq(float num, float sub, float s0, float s1, float atol, float rtol)
+{
+    const float q = (num - sub) / (atol + rtol * fmaxf(fabsf(s0), fabsf(s1)));
+    return (double)q * (double)q;
+}
+
 __global__ __launch_bounds__(256) void scaled_rms_kernel(const NormArgs a)
 {
     __shared__ double sh[4];
     __shared__ bool last;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const f32x4a zero4 = f32x4a{0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < a.n_terms; ++t) {
         double acc = 0.0;
-        for (long long i = tid; i < a.n[t]; i += stride) {
-            float v = a.num[t][i];
-            if (a.sub[t]) v -= a.sub[t][i];
-            float sc = fabsf(a.s0[t][i]);
-            if (a.s1[t]) sc = fmaxf(sc, fabsf(a.s1[t][i]));
-            const float q = v / (a.atol + a.rtol * sc);
-            acc += (double)q * (double)q;
+        const float* num = a.num[t]; const float* sub = a.sub[t]; const float* s0 = a.s0[t]; const float* s1 = a.s1[t];
+        const long long n4 = a.vec_ok[t] ? a.n[t] / 4 : 0;
+        for (long long i = tid; i < n4; i += stride) {
+            const f32x4a vn = ((const f32x4a*)num)[i];
+            const f32x4a vs = sub ? ((const f32x4a*)sub)[i] : zero4;
+            const f32x4a v0 = ((const f32x4a*)s0)[i];
+            const f32x4a v1 = s1 ? ((const f32x4a*)s1)[i] : zero4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += scaled_sq(vn[j], vs[j], v0[j], v1[j], a.atol, a.rtol);
         }
+        for (long long i = 4 * n4 + tid; i < a.n[t]; i += stride)      // unaligned input or the last n % 4 elements
+            acc += scaled_sq(num[i], sub ? sub[i] : 0.f, s0[i], s1 ? s1[i] : 0.f, a.atol, a.rtol);
         const double tot = block_sum(acc, sh);
         if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
     }
     {
         double bad = 0.0;
-        for (long long i = tid; i < a.n_check; i += stride) {
+        const long long n4 = a.check_vec_ok ? a.n_check / 4 : 0;
+        for (long long i = tid; i < n4; i += stride) {
+            const f32x4a v = ((const f32x4a*)a.check)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad += (v[j] - v[j] == 0.f) ? 0.0 : 1.0;        // NaN or infinity
+        }
+        for (long long i = 4 * n4 + tid; i < a.n_check; i += stride) {
             const float v = a.check[i];
-            bad += (v - v == 0.f) ? 0.0 : 1.0;        // NaN or infinity
+            bad += (v - v == 0.f) ? 0.0 : 1.0;
         }
         const double tot = block_sum(bad, sh);
         if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
@@ -154,13 +173,21 @@ __global__ __launch_bounds__(256) void scaled_rms_kernel(const NormArgs a)
         last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x <= (unsigned)a.n_terms) {
+    if (last) {
+        // the block that arrives last adds the partials up: thread i takes blocks i, i + 256, ... in that order, then the
+        // same fixed tree as above -- the grid size depends on the array sizes only, so equal inputs give equal sums
         __threadfence();
-        const int t = threadIdx.x < (unsigned)a.n_terms ? (int)threadIdx.x : FF_NORM_TERMS;
-        double tot = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) tot += a.partial[(size_t)b * (FF_NORM_TERMS + 1) + t];
-        if (t < FF_NORM_TERMS) a.out[threadIdx.x] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
-        else a.out[a.n_terms] = tot > 0.0 ? 1.f : 0.f;
+        for (int t = 0; t <= a.n_terms; ++t) {
+            const int col = t < a.n_terms ? t : FF_NORM_TERMS;
+            double acc = 0.0;
+            for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
+                acc += __builtin_nontemporal_load(&a.partial[(size_t)b * (FF_NORM_TERMS + 1) + col]);
+            const double tot = block_sum(acc, sh);
+            if (threadIdx.x == 0) {
+                if (t < a.n_terms) a.out[t] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
+                else a.out[a.n_terms] = tot > 0.0 ? 1.f : 0.f;
+            }
+        }
         if (threadIdx.x == 0) *a.counter = 0u;          // ready for the next launch on this stream
     }
 }
@@ -204,12 +231,14 @@ extern "C" int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float a
         k.num[t] = on ? terms[t].num : nullptr; k.sub[t] = on ? terms[t].sub : nullptr;
         k.s0[t] = on ? terms[t].scale0 : nullptr; k.s1[t] = on ? terms[t].scale1 : nullptr;
         k.n[t] = on ? terms[t].n : 0;
+        k.vec_ok[t] = ((((uintptr_t)k.num[t]) | ((uintptr_t)k.sub[t]) | ((uintptr_t)k.s0[t]) | ((uintptr_t)k.s1[t])) & 15) == 0;
         if (k.n[t] > most) most = k.n[t];
     }
+    k.check_vec_ok = (((uintptr_t)check) & 15) == 0;
     k.check = check; k.n_check = n_check; k.n_terms = n_terms; k.atol = atol; k.rtol = rtol; k.out = out;
     k.counter = (unsigned*)workspace;
     k.partial = (double*)((char*)workspace + 16);
-    long long want = (most + 255) / 256;
+    long long want = (most / 4 + 255) / 256;              // one 16-byte access per thread and trip
     const unsigned grid = (unsigned)(want < 1 ? 1 : (want > ff::kNormBlocks ? ff::kNormBlocks : want));
     hipLaunchKernelGGL(ff::scaled_rms_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, k);
     return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;

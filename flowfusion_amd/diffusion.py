@@ -29,7 +29,7 @@ from torch.distributions import Normal
 
 from . import adaptive, generic, solvers
 from . import host_stepper, trace_estimators
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,9 +257,17 @@ class ScoreModel(nn.Module):
 
     # -- any other `model=` module: native stepping around the module's own forward (generic.py) -------------
     def _fusable(self) -> bool:
-        """The score network is the reference's MLP (weights the fused kernels can hold)."""
+        """The score network is the reference's MLP and a compiled kernel holds its shape and activation.  Anything
+        else -- a user module, or an MLP wider / higher-dimensional than the compiled shapes or with an activation
+        the kernels do not implement -- is stepped by generic.py (the reference has no such limit, diffusion.py:59-72).
+        An explicit ``precision=`` other than f32 never switches arithmetic silently: ``_net()`` raises instead."""
         m = self.model
-        return hasattr(m, "NN") and hasattr(m, "W") and hasattr(m, "pi") and hasattr(m, "n_dimensions")
+        if not (hasattr(m, "NN") and hasattr(m, "W") and hasattr(m, "pi") and hasattr(m, "n_dimensions")):
+            return False
+        if getattr(self, "precision", "f32") != "f32":
+            return True
+        key = tuple(id(l) for l in m.NN) + (repr(m.activation),)
+        return within_envelope(self, key, self._net)
 
     def _rhs_module(self, t, y):
         """ODE right-hand side through ``self.forward`` (the reference's own RHS, diffusion.py:281-508): the user's

@@ -21,8 +21,8 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import adaptive, solvers
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec
+from . import adaptive, generic, solvers
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
 
 _DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
 
@@ -57,6 +57,48 @@ class _FlowBase(nn.Module):
             object.__setattr__(self, "_fused", FusedNet(lin, D, C, x_col0=0, c_col0=D + 1, act=act, precision=prec))
         return self._fused
 
+    def _fusable(self) -> bool:
+        """A compiled kernel holds the velocity network (shape and activation).  The reference has no limit on
+        either (flow.py:61-74, 494-508); outside the compiled shapes the solve goes through generic.py.  An explicit
+        ``precision=`` other than f32 never switches arithmetic silently: ``_net()`` raises instead."""
+        if getattr(self, "precision", "f32") != "f32":
+            return True
+        key = tuple(id(m) for m in self.layers) + tuple(repr(m) for m in self.layers if not isinstance(m, nn.Linear))
+        return within_envelope(self, key, self._net)
+
+    def _solve_generic(self, x, t_span, method, options, mode, atol, rtol, cond, probe, raw_cond, affine):
+        """The same solve around ``self.velocity`` evaluated by torch: stage combinations, error norms and step
+        control by the library (generic.py), divergences by autograd as in the reference (flow.py:122-166, 598-652)."""
+        D = self.target_dimension
+
+        def velocity(t, y):
+            cols = [y, t.reshape(1, 1).to(y.dtype).expand(y.shape[0], 1)]
+            if cond is not None:
+                cols.append(cond)
+            return self.velocity(torch.cat(cols, dim=1))
+
+        def rhs(t, y):
+            if mode == MODE_STATE:
+                with torch.no_grad():
+                    return velocity(t, y), None
+            with torch.enable_grad():
+                y = y.detach().requires_grad_(True)
+                v = velocity(t, y)
+                if mode == MODE_HUTCH:
+                    div = (torch.autograd.grad(v, y, probe)[0] * probe).sum(dim=1)
+                else:
+                    div = sum(torch.autograd.grad(v[:, i].sum(), y, retain_graph=True)[0][:, i] for i in range(D))
+            return v.detach(), div.detach()
+
+        if affine.get("in_shift") is not None:
+            x = (x - affine["in_shift"]) / affine["in_scale"]
+        extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
+        y, lp, stats = generic.solve(rhs, x, t_span, method, options, mode != MODE_STATE, atol, rtol, norm_only=extra)
+        self.last_solver_stats = stats
+        if affine.get("out_scale") is not None:
+            y = y * affine["out_scale"] + affine["out_shift"]
+        return y, lp
+
     def _schedule(self, t, first=None):
         """(a, b, c1) for real times t (fp32, CPU): xdot = NET([x, t, cond]) -> a = 0, b = 1,
         c1 = w_t * t + bias of the first layer (flow.py:112-118).  ``first`` = host copy of the first layer,
@@ -76,6 +118,8 @@ class _FlowBase(nn.Module):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
     def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, raw_cond=None, **affine):
+        if not self._fusable():
+            return self._solve_generic(x, t_span, method, options, mode, atol, rtol, cond, probe, raw_cond, affine)
         net = self._net()
         if method in solvers.NATIVE_ADAPTIVE:
             if any(v is not None for v in affine.values()):

@@ -7,7 +7,8 @@ time-dependent part: one evaluation table per solve (solvers.py).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+import warnings
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
@@ -42,6 +43,34 @@ def activation_spec(act) -> Tuple[int, float, float]:
     raise NotImplementedError(
         f"activation {act!r}: the fused gfx950 kernels implement SiLU (the reference default), Tanh, Sigmoid, "
         "ReLU, LeakyReLU, ELU, Softplus and GELU")
+
+
+class FusedEnvelopeWarning(UserWarning):
+    """A network no compiled kernel can hold is evaluated by torch on the GPU (stepping stays native)."""
+
+
+def within_envelope(owner, key, build: Callable[[], "FusedNet"]) -> bool:
+    """True if a compiled kernel holds the network ``build()`` describes (plans for the state-only and the
+    divergence-capable kernels exist).  The reference puts no limit on width, dimension, conditional inputs or
+    activation (flowfusion/diffusion.py:59-72, flow.py:61-74); outside the compiled shapes the front ends keep the
+    solve on the GPU by handing the network to ``generic.py`` -- the module evaluated by torch, every Runge-Kutta
+    combination, error norm and noise update by the library's kernels -- and say so once per network
+    (``FusedEnvelopeWarning``).  The answer is cached on ``owner`` under ``key`` (identity of the layers)."""
+    cached = owner.__dict__.get("_envelope")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    try:
+        net = build()
+        net.plan(MODE_STATE)
+        net.plan(MODE_EXACT)
+        ok = True
+    except NotImplementedError as e:
+        warnings.warn(f"{e} -- outside the fused kernels' envelope: this network is evaluated by torch on the GPU, "
+                      "time stepping stays in the library's kernels (flowfusion_amd.generic)",
+                      FusedEnvelopeWarning, stacklevel=4)
+        ok = False
+    object.__setattr__(owner, "_envelope", (key, ok))
+    return ok
 
 
 def exact_trace_passes(dim: int, tile: int) -> List[Tuple[int, int]]:

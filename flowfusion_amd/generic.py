@@ -99,7 +99,8 @@ class ModuleStepper:
         return step
 
 
-def solve(rhs: Rhs, x: torch.Tensor, t_span: torch.Tensor, method: str, options, has_lp: bool, atol: float, rtol: float):
+def solve(rhs: Rhs, x: torch.Tensor, t_span: torch.Tensor, method: str, options, has_lp: bool, atol: float, rtol: float,
+          norm_only=()):
     """``odeint(func, state, t_span, method=, atol=, rtol=, options=)`` for an external right-hand side: fixed-grid
     methods (solvers.FIXED_METHODS) and adaptive dopri5.  Returns (y [B, D], dlogp [B] or None) at ``t_span[-1]``."""
     from . import adaptive
@@ -108,7 +109,7 @@ def solve(rhs: Rhs, x: torch.Tensor, t_span: torch.Tensor, method: str, options,
     if method in solvers.NATIVE_ADAPTIVE:
         t = t_span.detach().to("cpu", torch.float32).double()
         sign = -1.0 if bool(t[0] > t[-1]) else 1.0
-        solver = adaptive.Dopri5(stepper.make_step(sign), has_lp, rtol, atol, options, method=method)
+        solver = adaptive.Dopri5(stepper.make_step(sign), has_lp, rtol, atol, options, norm_only=norm_only, method=method)
         lp0 = torch.zeros(x.shape[0], device=x.device) if has_lp else None
         y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]), x.detach().to(torch.float32).contiguous(), lp0)
         return y, lp, {"attempts": solver.n_attempts, "accepted": solver.n_accepted, "evaluations": stepper.n_evals}

@@ -231,11 +231,68 @@ def test_empty_batch_and_nan_flag():
     assert int(status.item()) == 0
 
 
-def test_unsupported_shapes_raise_on_gpu():
-    from flowfusion_amd import flow as Fm
-    f = Fm.ODEFlow(64, [2048] * 2).to(DEV).eval()                 # wider than any compiled kernel
-    with pytest.raises(NotImplementedError):
-        f.sample(torch.randn(8, 64, device=DEV), method="rk4", options={"step_size": 0.1})
+def test_networks_outside_the_compiled_envelope_solve_through_the_module_path():
+    """The reference puts no limit on width, dimension or activation (diffusion.py:59-72, flow.py:61-74).  Outside the
+    compiled kernels' envelope the solve stays on the GPU -- network evaluated by torch, stepping / error control /
+    noise updates by the library (generic.py) -- says so once (FusedEnvelopeWarning), and agrees with the oracle:
+    a 2048-wide flow (sample, exact-trace and Hutchinson log_prob, fixed grid and adaptive), a Mish score model
+    (ODE sampling, log_prob, Euler-Maruyama with the injected stream), a 140-dimensional score model.  An explicit
+    precision= never switches arithmetic silently: it still raises."""
+    from flowfusion_amd import diffusion as Dm, flow as Fm
+    from flowfusion_amd.fused import FusedEnvelopeWarning
+    from oracle import flowfusion_oracle as O
+    torch.manual_seed(5)
+    f = Fm.ConditionalODEFlow(6, 3, [2048, 64], target_shift=torch.randn(6), target_scale=torch.rand(6) + 0.5,
+                              conditional_shift=torch.randn(3), conditional_scale=torch.rand(3) + 0.5).eval()
+    sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
+    fo = O.FlowOracle(O.flow_params_from_state_dict(sd))
+    fo64 = O.FlowOracle(O.flow_params_from_state_dict(sd), dtype=torch.float64)
+    f = f.to(DEV)
+    xT, cond = torch.randn(50, 6), torch.randn(50, 3)
+    opts = {"step_size": 0.1}
+    with pytest.warns(FusedEnvelopeWarning, match="outside the fused kernels' envelope"):
+        got = f.sample(xT.to(DEV), cond.to(DEV), method="rk4", options=opts)
+    assert _state_err(got, fo.sample(xT, cond, "rk4", opts)) < STATE_TOL
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", FusedEnvelopeWarning)          # said once per network, not per call
+        x = xT[:20] * f.target_scale.cpu() + f.target_shift.cpu()
+        lp = f.log_prob(x.to(DEV), cond[:20].to(DEV), method="rk4", options=opts)
+        assert _logp_err(lp, fo64.log_prob(x.double(), cond[:20].double(), "rk4", opts).float()) < LOGP_TOL
+        lpa = f.log_prob(x.to(DEV), cond[:20].to(DEV))                                       # adaptive dopri5 default
+        assert _logp_err(lpa, fo64.log_prob(x.double(), cond[:20].double(), "dopri5", None, atol=1e-5, rtol=1e-5).float()) < 2e-4
+        ga = f.sample(xT.to(DEV), cond.to(DEV))
+        assert _state_err(ga, fo64.sample(xT.double(), cond.double(), "dopri5", None, atol=1e-9, rtol=1e-7).float()) < 2e-4
+    f.precision = "bf16x3"
+    with pytest.raises(NotImplementedError, match="bf16x3"):
+        f.sample(xT.to(DEV), cond.to(DEV), method="rk4", options=opts)
+
+    # an activation the kernels do not implement, and more dimensions than any compiled kernel
+    for act, D, C, units in ((torch.nn.Mish(), 5, 2, [64, 64]), (torch.nn.SiLU(), 140, 0, [96])):
+        torch.manual_seed(11 + D)
+        sm = Dm.ScoreModel(Dm.MLP(D, C, 8, units, activation=act), Dm.VPSDE(), no_sigma=True).eval()
+        params = O.mlp_params_from_state_dict({k: v.detach().clone() for k, v in sm.state_dict().items()})
+        so32 = O.ScoreOracle(params, O.VP(), no_sigma=True, activation=act)
+        so64 = O.ScoreOracle(params, O.VP(dtype=torch.float64), no_sigma=True, dtype=torch.float64, activation=act)
+        sm = sm.to(DEV)
+        base = torch.randn(40, D)
+        cond = torch.randn(40, C) if C else None
+        cd = None if cond is None else cond.to(DEV)
+        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
+        with pytest.warns(FusedEnvelopeWarning):
+            x0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cd, method="rk4", options=opts)
+        assert _state_err(x0, so32.sample_ode_from_base(base, cond, "rk4", opts)) < STATE_TOL
+        sm.hutch = True
+        lp = sm.log_prob(base[:12].to(DEV), conditional=None if cd is None else cd[:12], method="rk4", options=opts)
+        ref = so64.log_prob(base[:12].double(), None if cond is None else cond[:12].double(), "rk4", opts, "hutch", sm.e.cpu().double())
+        assert _logp_err(lp, ref.float()) < LOGP_TOL
+        sm.hutch = False
+        prior = torch.randn(16, D)
+        draws = [torch.randn(16, D) for _ in range(8)]
+        it = iter(draws)
+        got = sm._sample_sde_from(prior.to(DEV), lambda like: next(it).to(DEV), None if cd is None else cd[:16], 8)
+        ref = so32.sample_sde(prior, draws, None if cond is None else cond[:16], steps=8)
+        assert _state_err(got, ref) < STATE_TOL
 
 
 def test_exact_trace_in_several_passes():

@@ -79,9 +79,18 @@ def test_no_cpu_fallback(built_library):
         sm.sample_ode_from_base(torch.randn(8, 4))                # reference default method=dopri5 (adaptive)
     with pytest.raises(NotImplementedError, match="adaptive"):
         sm.sample_ode_from_base(torch.randn(8, 4), method="dopri8")
+    # outside the compiled envelope (an activation the kernels do not implement): said once, and still GPU only
+    from flowfusion_amd.fused import FusedEnvelopeWarning
+    mish = D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Mish()), D.VPSDE()).eval()
+    with pytest.warns(FusedEnvelopeWarning), pytest.raises(RuntimeError, match="GPU"):
+        mish.sample_ode_from_base(torch.randn(8, 4), method="euler")
+    assert not mish._fusable() and sm._fusable()
+    wide = F.ODEFlow(3, [4096, 64])
+    with pytest.warns(FusedEnvelopeWarning), pytest.raises(RuntimeError, match="GPU"):
+        wide.sample(torch.randn(4, 3), method="rk4", options={"step_size": 0.1})
+    mish.precision = "bf16x3"                                    # an explicit arithmetic never switches silently
     with pytest.raises(NotImplementedError):
-        D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Mish()), D.VPSDE()).eval() \
-            .sample_ode_from_base(torch.randn(8, 4), method="euler")
+        mish.sample_ode_from_base(torch.randn(8, 4), method="euler")
     f = F.ODEFlow(3, [64, 64])
     with pytest.raises(RuntimeError, match="GPU"):
         f.sample(torch.randn(4, 3))                              # adaptive dopri5 default, as in the reference
