@@ -23,8 +23,9 @@
 //
 // Loop order: k-major.  A layer keeps ALL its 16 row tiles x 2 column blocks live (128 registers) and walks the
 // k-steps (32 features each); k-step s needs exactly row tiles 2s, 2s+1 of the previous layer, whose SiLU + split
-// (~12 VALU instructions per element, cut into four stages issued one group apart) is done one k-step ahead, in the
-// shadow of that k-step's 192 MFMAs.  Two sets of tiles ping-pong between consecutive layers; a tile is refilled with
+// (~12 VALU instructions per element) is done one k-step ahead, in the shadow of that k-step's 192 MFMAs: cut into
+// micro-ops of at most two instructions, each pinned behind one particular MFMA (GapPlan below; full scheduling
+// barriers make the instruction stream the one written here).  Two sets of tiles ping-pong between consecutive layers; a tile is refilled with
 // the bias of its next use (from LDS) as soon as it has been consumed, so the MFMA chain adds the bias.
 //
 // Weights: every wavefront needs every fragment, so they are staged through LDS and shared by the workgroup.  The
@@ -100,65 +101,146 @@ __device__ __forceinline__ float from_value_lane(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));
 }
 
-// Activation + split of one UNIT = two pre-activations -> one word of the three fragments, cut into four stages that
-// are issued one GROUP (12 MFMAs, ~190 cycles) apart, so that no instruction waits on a transcendental issued just
-// before it: the wavefront issues in order, and a VALU instruction stalled on its operand holds the next MFMA behind
-// it.  Between stages a unit lives in four registers.  Value columns: SiLU(a).  Tangent columns (forward-mode
-// derivative through the same weights): a' * SiLU'(a of the sample's value column), SiLU'(a) = s + a s (1 - s).
+// Activation + split of one UNIT = two pre-activations -> one word of the three fragments, cut into MICRO-OPS of at
+// most two plain VALU instructions or one transcendental: what fits the 8 cycles of vector issue a 16-cycle MFMA
+// leaves free (MI355X_MICROARCH.md, issue costs).  Every micro-op is pinned behind one particular MFMA (a GAP; plan
+// below): left to the list scheduler the same instructions clump -- four or five behind one MFMA, none behind the next
+// six -- and every instruction past the free 8 cycles delays the matrix pipe by its full issue time.  Value columns:
+// SiLU(a).  Tangent columns (forward-mode derivative through the same weights): a' * SiLU'(a of the sample's value
+// column), SiLU'(a) = s + a s (1 - s).
+#ifndef FF_SPLIT_AHEAD
+#define FF_SPLIT_AHEAD 1
+#endif
+constexpr int kAhead = FF_SPLIT_AHEAD;      // groups between the LDS read of a weight fragment and its MFMAs
+
 struct UnitState {
-    float a0, a1, t0, t1;
+    float a0, a1, t0, t1, h0, h1, o0, o1;      // (h, o: tangent kernels only)
 };
-template <bool TANGENTS, int STAGE>
-__device__ __forceinline__ void unit_stage(float pre0, float pre1, UnitState& u, u32x4 (&frag)[3], int word, bool is_tangent)
+enum MicroOp {
+    M_LOAD, M_SCALE, M_EXP0, M_EXP1, M_ADD1, M_RCP0, M_RCP1, M_VALUE,
+    M_TV_H, M_TV_OMS, M_TV_SLOPE, M_TV_DPP, M_TV_MUL, M_TV_SEL,           // tangent kernels: in place of M_VALUE
+    M_TOPH, M_RESM, M_PACKH, M_PACKM, M_RESL, M_PACKL
+};
+FF_HD constexpr int micro_count(bool tangents) { return tangents ? 19 : 14; }
+FF_HD constexpr int micro_op(bool tangents, int j)
+{
+    if (j < 7) return j;                                   // M_LOAD .. M_RCP1
+    if (!tangents) return j == 7 ? M_VALUE : M_TOPH + (j - 8);
+    return j < 13 ? M_TV_H + (j - 7) : M_TOPH + (j - 13);
+}
+template <bool TANGENTS, int J>
+__device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u, u32x4 (&frag)[3], int word, bool is_tangent)
 {
     constexpr float NLOG2E = -1.44269504088896340736f;
-    if constexpr (STAGE == 0) {            // pre-activations out of the accumulator; exp(-a)
+    constexpr int OP = micro_op(TANGENTS, J);
+#ifdef FF_SPLIT_SKIP_OPS        // timing experiments only: bit OP set = that micro-op is left out (wrong results)
+    if constexpr (((FF_SPLIT_SKIP_OPS) >> OP) & 1) return;
+#endif
+    if constexpr (OP == M_LOAD) {              // pre-activations out of the accumulator tile (AGPR -> VGPR copies, here)
         u.a0 = pre0;
         u.a1 = pre1;
-#ifdef FF_SPLIT_NOACT           // timing experiment only: identity activation (wrong results)
-        u.t0 = u.a0; u.t1 = u.a1;
-#else
-        u.t0 = __builtin_amdgcn_exp2f(u.a0 * NLOG2E);
-        u.t1 = __builtin_amdgcn_exp2f(u.a1 * NLOG2E);
-#endif
-    } else if constexpr (STAGE == 1) {     // sigmoid
-#ifndef FF_SPLIT_NOACT
-        u.t0 = __builtin_amdgcn_rcpf(1.0f + u.t0);
-        u.t1 = __builtin_amdgcn_rcpf(1.0f + u.t1);
-#endif
-    } else if constexpr (STAGE == 2) {     // activation value; first residual
-#ifdef FF_SPLIT_NOACT
-        const float h0 = u.a0, h1 = u.a1;
-#else
-        float h0 = u.a0 * u.t0, h1 = u.a1 * u.t1;
-        if constexpr (TANGENTS) {
-            const float d0 = from_value_lane(__builtin_fmaf(h0, 1.0f - u.t0, u.t0));
-            const float d1 = from_value_lane(__builtin_fmaf(h1, 1.0f - u.t1, u.t1));
-            h0 = is_tangent ? u.a0 * d0 : h0;
-            h1 = is_tangent ? u.a1 * d1 : h1;
-        }
-#endif
-        u.a0 = h0;
-        u.a1 = h1;
-#ifndef FF_SPLIT_NOSPLIT        // timing experiment only: the three parts are all the top half (wrong results)
-        u.t0 = h0 - top(h0);
-        u.t1 = h1 - top(h1);
-#endif
-    } else {                               // second residual and the three packed words
-#ifdef FF_SPLIT_NOSPLIT
-        frag[0][word] = frag[1][word] = frag[2][word] = pack_hi(u.a0, u.a1);
-#else
-        const float l0 = u.t0 - top(u.t0), l1 = u.t1 - top(u.t1);
+        asm volatile("" : "+v"(u.a0), "+v"(u.a1));
+    } else if constexpr (OP == M_SCALE) {
+        u.t0 = u.a0 * NLOG2E;
+        u.t1 = u.a1 * NLOG2E;
+    } else if constexpr (OP == M_EXP0) {
+        u.t0 = __builtin_amdgcn_exp2f(u.t0);
+    } else if constexpr (OP == M_EXP1) {
+        u.t1 = __builtin_amdgcn_exp2f(u.t1);
+    } else if constexpr (OP == M_ADD1) {
+        u.t0 = 1.0f + u.t0;
+        u.t1 = 1.0f + u.t1;
+    } else if constexpr (OP == M_RCP0) {       // sigmoid
+        u.t0 = __builtin_amdgcn_rcpf(u.t0);
+    } else if constexpr (OP == M_RCP1) {
+        u.t1 = __builtin_amdgcn_rcpf(u.t1);
+    } else if constexpr (OP == M_VALUE) {      // SiLU
+        u.a0 = u.a0 * u.t0;
+        u.a1 = u.a1 * u.t1;
+    } else if constexpr (OP == M_TV_H) {
+        u.h0 = u.a0 * u.t0;
+        u.h1 = u.a1 * u.t1;
+    } else if constexpr (OP == M_TV_OMS) {     // h (1 - s)
+        u.o0 = __builtin_fmaf(-u.h0, u.t0, u.h0);
+        u.o1 = __builtin_fmaf(-u.h1, u.t1, u.h1);
+    } else if constexpr (OP == M_TV_SLOPE) {   // SiLU'(a) = s + h (1 - s)
+        u.t0 = u.o0 + u.t0;
+        u.t1 = u.o1 + u.t1;
+    } else if constexpr (OP == M_TV_DPP) {     // tangent lanes: the slope of their sample's value column
+        u.t0 = from_value_lane(u.t0);
+        u.t1 = from_value_lane(u.t1);
+    } else if constexpr (OP == M_TV_MUL) {
+        u.o0 = u.a0 * u.t0;
+        u.o1 = u.a1 * u.t1;
+    } else if constexpr (OP == M_TV_SEL) {
+        u.a0 = is_tangent ? u.o0 : u.h0;
+        u.a1 = is_tangent ? u.o1 : u.h1;
+    } else if constexpr (OP == M_TOPH) {       // three-way split of the activation value (a0, a1)
+        u.t0 = top(u.a0);
+        u.t1 = top(u.a1);
+    } else if constexpr (OP == M_RESM) {
+        u.t0 = u.a0 - u.t0;
+        u.t1 = u.a1 - u.t1;
+    } else if constexpr (OP == M_PACKH) {
         frag[0][word] = pack_hi(u.a0, u.a1);
+        u.a0 = top(u.t0);
+    } else if constexpr (OP == M_PACKM) {
+        u.a1 = top(u.t1);
         frag[1][word] = pack_hi(u.t0, u.t1);
-        frag[2][word] = pack_hi(l0, l1);
-#endif
+    } else if constexpr (OP == M_RESL) {
+        u.a0 = u.t0 - u.a0;
+        u.a1 = u.t1 - u.a1;
+    } else {
+        frag[2][word] = pack_hi(u.a0, u.a1);
     }
 }
-// Schedule of the 8 units of a k-step's operands over the groups of a span: unit u starts at group start(u), stage k
-// runs at group start(u) + k.  kind 0: the 16 groups of the k-step before (starts 0,1,3,4,6,7,9,10); kind 1: the 14
-// groups after row tiles 0 and 1 of a layer's own output are complete (starts 2 + u).
-FF_HD constexpr int unit_start(int kind, int u) { return kind == 0 ? (3 * u) / 2 : 2 + u; }
+
+// GAP PLAN of a span of 16 groups = 192 MFMAs (one k-step of a hidden layer, or the whole first layer): which micro-op
+// of which of the 8 units (a k-step's operands: 2 column blocks x 4 words) sits behind MFMA g of the span.  Built
+// greedily: a unit's micro-ops are at least two gaps apart (nothing waits on the instruction before it), a gap holds one
+// micro-op, and the gaps that carry an LDS-DMA (the even gaps of the groups that open a granule) hold none.  Units of
+// span kind 1 read row tiles 0 and 1 of the span's OWN output, complete after groups 0 and 1: they start at gap 24.
+constexpr int kSpanGaps = 16 * 12;
+#ifndef FF_SPLIT_SPACING
+#define FF_SPLIT_SPACING 2
+#endif
+constexpr int kMicroSpacing = FF_SPLIT_SPACING;      // gaps between consecutive micro-ops of a unit
+struct GapPlan {
+    signed char unit[kSpanGaps];
+    signed char micro[kSpanGaps];
+    bool ok;
+};
+FF_HD constexpr GapPlan make_gap_plan(bool tangents, int first_gap)
+{
+    GapPlan p{};
+    bool dma[kSpanGaps] = {};
+    for (int g = 0; g < kSpanGaps; ++g) {
+        p.unit[g] = -1;
+        p.micro[g] = -1;
+        dma[g] = ((g / 12) % kGranuleGroups == 0) && ((g % 12) % 2 == 0);
+    }
+    p.ok = true;
+    for (int u = 0; u < 8; ++u) {
+        int g = first_gap;
+        for (int j = 0; j < micro_count(tangents); ++j) {
+            while (g < kSpanGaps && (dma[g] || p.unit[g] >= 0)) ++g;
+            if (g >= kSpanGaps) {
+                p.ok = false;
+                return p;
+            }
+            p.unit[g] = (signed char)u;
+            p.micro[g] = (signed char)j;
+            g += kMicroSpacing;
+        }
+    }
+    return p;
+}
+template <bool TANGENTS>
+struct GapPlans {
+    static constexpr GapPlan k0 = make_gap_plan(TANGENTS, 0);
+    static constexpr GapPlan k1 = make_gap_plan(TANGENTS, 24);
+    static_assert(k0.ok && k1.ok, "the activation micro-ops of a k-step do not fit its 192 gaps");
+};
 
 // LDS-DMA of one fragment: 64 lanes x 16 bytes from `g` (wave-uniform) + lane * 16 to LDS byte `lds_byte` + lane * 16.
 // Inline asm on purpose: as a builtin the DMA makes hipcc spill, and every spill reload then queues behind it.
@@ -251,6 +333,20 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) kl[s][0] = kl[s][1] = 0.f;
     float lp[2] = {0.f, 0.f};
+#ifdef FF_SPLIT_STAMPS          // diagnostic builds only (scratch/kbench_split.hip): cycle stamps of wavefront 0, evaluations 2 and 3
+    int stamp_i = 0;
+    bool stamp_on = false;
+#define FF_STAMP()                                                                                         \
+    do {                                                                                                   \
+        if (stamp_on) {                                                                                    \
+            const unsigned long long t_ = __builtin_readcyclecounter();                                    \
+            if (lane == 0) args.debug_stamps[stamp_i] = t_;                                                \
+            ++stamp_i;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+#else
+#define FF_STAMP() do {} while (0)
+#endif
 
     // ---- weight pipeline state (all wave-uniform) -----------------------------------------------------------------
     const unsigned char* const wbase = (const unsigned char*)args.wpack;
@@ -258,24 +354,17 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     long long dpos = 0;                                // byte position in the stream of the NEXT granule to fetch
     unsigned rbuf = 0;                                 // LDS byte offset of the buffer the current granule is read from
     const int my_frag = wv * 6 * 1024;                 // this wavefront's quarter of a granule
-    auto fetch_granule = [&](unsigned wbuf) __attribute__((always_inline)) {
-        // The stream position is periodic in the evaluation loop, so hipcc would compute all ~300 fragment addresses
-        // of an evaluation once, ahead of the loop, and keep them in (spilled) SGPRs: hide the two bases from it.
-        const unsigned char* src = wbase + dpos + my_frag;
-        unsigned dst = wbuf + my_frag;
-        asm volatile("" : "+s"(src), "+s"(dst));
-#pragma unroll
-        for (int f = 0; f < 6; ++f) dma_fragment(dst + f * 1024, src + f * 1024, lane16);
-        dpos += GB;
-        if (dpos >= wbytes) dpos = 0;
-    };
     auto fetch_c1 = [&](int e) __attribute__((always_inline)) {      // c1 of evaluation e -> its LDS buffer (every wavefront issues
         const int ee_ = e < args.n_evals ? e : 0;                      // the same 1 KiB copy: equal VMEM counts keep the counted waits uniform)
         dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32), lane16);
     };
     fetch_c1(0);
-    fetch_granule(0);
-    fetch_granule(GB);
+    for (int g = 0; g < 2; ++g) {                      // granules 0 and 1 into buffers 0 and 1
+#pragma unroll
+        for (int f = 0; f < 6; ++f) dma_fragment(g * GB + my_frag + f * 1024, wbase + dpos + my_frag + f * 1024, lane16);
+        dpos += GB;
+        if (dpos >= wbytes) dpos = 0;
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -293,71 +382,104 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         B[rt][0] = B[rt][1] = bias_tile(M.hbias, rt);  // (unused when there is a single hidden layer)
     }
 
-    // weight fragments of the current group (w) and the next one (wn), read from LDS one group ahead
-    u32x4 w[3], wn[3];
+    // weight fragments of the current group (wq[0]) and of the kAhead groups after it, read from LDS kAhead groups
+    // ahead (one group = 192 cycles is enough: distances 2 and 3 measured the same to 0.1 %)
+    u32x4 wq[kAhead + 1][3];
     int wa = lane16;                                   // LDS address of this lane's 16 bytes of fragment 0 of the granule
     int wa_next = lane16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) w[p] = *(const u32x4*)(lds + wa + p * 1024);
+    for (int a = 0; a < kAhead; ++a)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wq[a][p] = *(const u32x4*)(lds + wa + (a * 3 + p) * 1024);
 
-    // Called before the MFMAs of group GQ (0..7) of a granule.
-    auto pre = [&](auto gq) __attribute__((always_inline)) {
+    // ONE GROUP: 12 MFMAs = six products x two column blocks, in an order where consecutive MFMAs never depend on each
+    // other, each followed by what is pinned to its gap -- one fragment read of the next group (gaps 1, 5, 9), in the
+    // group that opens a granule one LDS-DMA of granule + 2 (even gaps), and `fill(gap)`, the caller's activation
+    // micro-op -- and a full scheduling barrier, so that the instruction stream is the one written here.  GQ = the
+    // group's index in its granule.
+    auto group = [&](auto gq, f32x4 (&acc)[2], const u32x4 (&b)[2][3], auto&& fill) __attribute__((always_inline)) {
         constexpr int GQ = decltype(gq)::value;
+        const unsigned char* dsrc = nullptr;
+        unsigned ddst = 0;
         if constexpr (GQ == 0) {
-            asm volatile("" : "+s"(rbuf));             // (periodic over evaluations as well: keep it a run-time value)
+            // The stream position is periodic in the evaluation loop, so hipcc would compute all ~300 fragment
+            // addresses of an evaluation once, ahead of the loop, and keep them in (spilled) SGPRs: hide the bases.
+            asm volatile("" : "+s"(rbuf));
             unsigned wb = rbuf + 2 * GB;
-            if (wb >= 3 * GB) wb -= 3 * GB;
-#ifndef FF_SPLIT_NODMA          // timing experiment only: never refresh the weight buffers (wrong results)
-            fetch_granule(wb);                         // granule + 2 -> the buffer read before this one
-#endif
+            if (wb >= 3 * GB) wb -= 3 * GB;            // granule + 2 -> the buffer read before this one
+            dsrc = wbase + dpos + my_frag;
+            ddst = wb + my_frag;
+            asm volatile("" : "+s"(dsrc), "+s"(ddst));
+            dpos += GB;
+            if (dpos >= wbytes) dpos = 0;
         }
-        if constexpr (GQ == 7) {
-            // everything but the six DMAs just issued has landed, and this wavefront's reads of the current buffer
-            // have returned: after the barrier the next granule is visible to all and the previous buffer is free
+        if constexpr (GQ == kGranuleGroups - kAhead) {
+            // everything but the six DMAs issued in this granule has landed, and this wavefront's reads of the current
+            // buffer have returned: after the barrier the next granule is visible to all and the previous buffer is free
             asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-#ifndef FF_SPLIT_NOBARRIER      // timing experiment only (with FF_SPLIT_NODMA)
+#ifndef FF_SPLIT_NOBARRIER       // timing experiment only (with FF_SPLIT_NODMA)
             __builtin_amdgcn_s_barrier();
 #endif
             rbuf += GB;
             if (rbuf >= 3 * GB) rbuf = 0;
             wa_next = lane16 + rbuf;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(lds + wa_next + p * 1024);
-        } else {
-#ifndef FF_SPLIT_NOWREAD        // timing experiment only: one group's fragments serve the whole granule (wrong results)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wn[p] = *(const u32x4*)(lds + wa + ((GQ + 1) * 3 + p) * 1024);
-#else
-#pragma unroll
-            for (int p = 0; p < 3; ++p) wn[p] = w[p];
-#endif
         }
-    };
-    auto post = [&](auto gq) __attribute__((always_inline)) {
-        constexpr int GQ = decltype(gq)::value;
+        sfor<12>([&](auto ii) {
+            constexpr int I = decltype(ii)::value;
+            constexpr int cb = I & 1, pr = I >> 1;
+            constexpr int wp = (pr == 2 || pr == 4) ? 1 : (pr == 5 ? 2 : 0);        // hh hm mh hl mm lh
+            constexpr int bp = (pr == 1 || pr == 4) ? 1 : (pr == 3 ? 2 : 0);
+            acc[cb] = mm(wq[0][wp], b[cb][bp], acc[cb]);
+#ifdef FF_SPLIT_NOWREAD          // timing experiment only: one group's fragments serve the whole granule (wrong results)
+            if constexpr (I % 4 == 1 && GQ == 0) {
+#else
+            if constexpr (I % 4 == 1) {
+#endif
+                constexpr int part = I / 4, T = GQ + kAhead;            // fragments of the group kAhead groups on
+                if constexpr (T >= kGranuleGroups) wq[kAhead][part] = *(const u32x4*)(lds + wa_next + ((T - kGranuleGroups) * 3 + part) * 1024);
+                else wq[kAhead][part] = *(const u32x4*)(lds + wa + (T * 3 + part) * 1024);
+            }
+#ifndef FF_SPLIT_NODMA           // timing experiment only: never refresh the weight buffers (wrong results)
+            if constexpr (GQ == 0 && (I & 1) == 0) dma_fragment(ddst + (I / 2) * 1024, dsrc + (I / 2) * 1024, lane16);
+#endif
+            fill(ii);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef FF_SPLIT_NOWREAD
+        if constexpr (GQ == 0)
+#endif
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = wn[p];
-        if constexpr (GQ == 7) wa = wa_next;
-        // MFMAs, LDS and vector-memory instructions keep their order; VALU / SALU / transcendentals may move
-        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x400);
+        for (int a = 0; a < kAhead; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wq[a][p] = wq[a + 1][p];
+        if constexpr (GQ == kGranuleGroups - 1) wa = wa_next;
     };
+    auto no_fill = [](auto) {};
 
     u32x4 bf[2][2][3];                                 // B fragments [k-step parity][column block][part] in use / in preparation
-    UnitState us[8];                                   // activation units in flight (four stages, one group apart)
+    UnitState us[8];                                   // activation units in flight
+#ifdef FF_SPLIT_SKIP_OPS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) us[i] = UnitState{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) bf[i][j][k] = u32x4{0u, 0u, 0u, 0u};
+#endif
 
-    // Stages of the units that turn row tiles (2 sn, 2 sn + 1) of `T` into the fragments of k-step sn, falling on group
-    // G of a span (schedule `KIND`).  Unit u: column block u >> 2, word u & 3 = registers 2 (u & 1), 2 (u & 1) + 1 of row
-    // tile 2 sn + ((u >> 1) & 1).
-    auto act_at = [&](auto kind, auto gg, auto snn, f32x4 (&T)[NR][2], u32x4 (&dst)[2][3]) __attribute__((always_inline)) {
+    // The micro-op the plan `KIND` pins to gap G of a span: the units turn row tiles (2 sn, 2 sn + 1) of `T` into the
+    // fragments of k-step sn.  Unit u: column block u >> 2, word u & 3 = registers 2 (u & 1), 2 (u & 1) + 1 of row tile
+    // 2 sn + ((u >> 1) & 1).
+    auto act_gap = [&](auto kind, auto gg, auto snn, f32x4 (&T)[NR][2], u32x4 (&dst)[2][3]) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind)::value, G = decltype(gg)::value, sn = decltype(snn)::value;
-        sfor<8>([&](auto uu) {
-            constexpr int U = decltype(uu)::value;
-            constexpr int k = G - unit_start(KIND, U);
-            if constexpr (k >= 0 && k < 4) {
-                constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
-                unit_stage<TANGENTS, k>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
-            }
-        });
+        constexpr int U = KIND == 0 ? GapPlans<TANGENTS>::k0.unit[G] : GapPlans<TANGENTS>::k1.unit[G];
+        if constexpr (U >= 0) {
+            constexpr int J = KIND == 0 ? GapPlans<TANGENTS>::k0.micro[G] : GapPlans<TANGENTS>::k1.micro[G];
+            constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
+            unit_micro<TANGENTS, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
+        }
     };
 
     // A hidden -> hidden layer (reads P, writes Cc) or, with OUT, the output layer (reads P, writes O).
@@ -368,40 +490,56 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         P[1][0] = P[1][1] = bias_tile(refill, 1);
         sfor<NS>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
-            constexpr int NTILE = OUT ? 1 : NR;
-            sfor<NTILE>([&](auto tt) {
-                constexpr int rt = decltype(tt)::value;
-                constexpr int q = s * NTILE + rt;
-                pre(std::integral_constant<int, q % 8>{});
-                if constexpr (OUT) group12(O, w, bf[s & 1]);
-                else group12(Cc[rt], w, bf[s & 1]);
-                // activation stages in the shadow of the MFMAs just issued
-                if constexpr (OUT) {
-                    if constexpr (s < NS - 1) {        // one group per k-step: all eight units, whole (the output layer is VALU-bound)
+            if constexpr (OUT) {
+                // one group per k-step: the output layer is VALU-bound, its activation units run whole behind the group,
+                // interleaved so that eight independent chains cover each other's latencies
+                group(std::integral_constant<int, s % 8>{}, O, bf[s & 1], no_fill);
+                if constexpr (s < NS - 1) {
+                    sfor<micro_count(TANGENTS)>([&](auto jj) {
                         sfor<8>([&](auto uu) {
                             constexpr int U = decltype(uu)::value;
                             constexpr int cb = U >> 2, word = U & 3, prt = 2 * (s + 1) + (word >> 1), r0 = 2 * (word & 1);
-                            sfor<4>([&](auto kk) {
-                                unit_stage<TANGENTS, decltype(kk)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
-                                                                         bf[(s + 1) & 1][cb], word, is_tangent);
-                            });
+                            unit_micro<TANGENTS, decltype(jj)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
+                                                                     bf[(s + 1) & 1][cb], word, is_tangent);
                         });
-                    }
-                } else if constexpr (s < NS - 1) {
-                    act_at(std::integral_constant<int, 0>{}, tt, std::integral_constant<int, s + 1>{}, P, bf[(s + 1) & 1]);
-                } else {                               // last k-step: row tiles 0, 1 of THIS layer's output, complete after groups 0, 1
-                    act_at(std::integral_constant<int, 1>{}, tt, std::integral_constant<int, 0>{}, Cc, bf[0]);
+                    });
                 }
-                post(std::integral_constant<int, q % 8>{});
-            });
+            } else {
+                sfor<NR>([&](auto tt) {
+                    constexpr int rt = decltype(tt)::value;
+#ifdef FF_SPLIT_STAMP_GROUPS    // diagnostic: a stamp per group of k-step 3 (every hidden layer)
+                    if constexpr (s == 3) FF_STAMP();
+#endif
+                    group(std::integral_constant<int, rt % 8>{}, Cc[rt], bf[s & 1], [&](auto ii) {
+                        constexpr int G = rt * 12 + decltype(ii)::value;
+#ifdef FF_SPLIT_STAMP_GAPS      // diagnostic: a stamp behind every MFMA of groups 0 and 1 of k-step 3
+                        if constexpr (s == 3 && rt < 2) FF_STAMP();
+#endif
+#ifdef FF_SPLIT_UNITS_EVEN_ONLY   // diagnostic: the activation units run in k-steps 0, 2, 4, 6 only (wrong results)
+                        if constexpr (s % 2 == 1) return;
+#endif
+                        if constexpr (s < NS - 1)       // the operands of the next k-step, out of the layer before
+                            act_gap(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{},
+                                    std::integral_constant<int, s + 1>{}, P, bf[(s + 1) & 1]);
+                        else                            // last k-step: row tiles 0, 1 of THIS layer's output
+                            act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, G>{},
+                                    std::integral_constant<int, 0>{}, Cc, bf[0]);
+                    });
+                });
+            }
             if constexpr (s < NS - 1) {                // row tiles 2s+2, 2s+3 were consumed during this k-step
                 P[2 * s + 2][0] = P[2 * s + 2][1] = bias_tile(refill, 2 * s + 2);
                 P[2 * s + 3][0] = P[2 * s + 3][1] = bias_tile(refill, 2 * s + 3);
             }
+            FF_STAMP();
         });
     };
 
     for (int e = 0; e < args.n_evals; ++e) {
+#ifdef FF_SPLIT_STAMPS
+        stamp_on = args.debug_stamps && blockIdx.x == 0 && wv == 0 && (e == 2 || e == 3);
+#endif
+        FF_STAMP();
         HdrPtr hdr = (HdrPtr)(args.etab + (size_t)e * args.etab_stride);
         const float a_e = hdr->a, b_e = hdr->b;
         const uint32_t flags = hdr->flags;
@@ -418,19 +556,20 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             split2(v[2], v[3], yf[cb], 1);
         }
 
+        FF_STAMP();
         // ---- layer 1: [state | conditional] (one k-step) -> H, accumulators A already hold c1_e --------------------
         sfor<NR>([&](auto tt) {
             constexpr int rt = decltype(tt)::value;
-            pre(std::integral_constant<int, rt % 8>{});
-#ifndef FF_SPLIT_NODMA
-            if constexpr (rt == 0) fetch_c1(e + 1);                    // (after the weight DMAs of this granule)
-#endif
-            group12(A[rt], w, yf);
-            // row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
-            act_at(std::integral_constant<int, 1>{}, tt, std::integral_constant<int, 0>{}, A, bf[0]);
-            post(std::integral_constant<int, rt % 8>{});
+            group(std::integral_constant<int, rt % 8>{}, A[rt], yf, [&](auto ii) {
+                constexpr int I = decltype(ii)::value;
+                if constexpr (rt == 0 && I == 11) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
+                // row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
+                act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, rt * 12 + I>{},
+                        std::integral_constant<int, 0>{}, A, bf[0]);
+            });
         });
 
+        FF_STAMP();
         // ---- hidden -> hidden layers, ping-pong A -> B -> A ..., then the output layer ------------------------------
         // refill address of the set being READ by layer j (1-based; j = NH is the output layer): the bias of the next
         // layer that writes that set -- layer j+1 of this evaluation if it is a hidden one, else the first layer of the
@@ -454,6 +593,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             }
         });
 
+        FF_STAMP();
         // ---- right-hand side and stage bookkeeping ------------------------------------------------------------------
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {

@@ -3,6 +3,7 @@
 #   (select it with FLOWFUSION_AMD_LIB=OUT.so); timing ablations: -DFF_SPLIT_NODMA -DFF_SPLIT_NOACT -DFF_SPLIT_NOBARRIER
 set -e
 OUT=$1; FLAGS=$2; NAME=${3:-mlp_ode_split_h256_n4_t0}; ROW=${4:-4,0}
+# FLAGS may carry -I<dir> to take an older ff_mlp_ode_split.hpp first (e.g. -Iscratch/split_v1: the kernel before the pinned gaps)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=$(mktemp -d)
 hipcc -O3 -std=c++17 -fPIC -Wno-inline-asm -x hip --offload-arch=gfx950 $FLAGS -I$R/flowfusion_amd/csrc -I$R/include -c $R/flowfusion_amd/_build/gen/$NAME.hip -o $T/k.o
