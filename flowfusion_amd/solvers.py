@@ -144,15 +144,31 @@ def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict]) -> Eval
     options = dict(options or {})
     step_size = options.pop("step_size", None)
     options.pop("min_step", None)      # adaptive-only knob (the reference's log_prob default passes it)
-    for k in ("grid_constructor", "perturb", "interp"):
-        if options.get(k) not in (None, False, "linear"):
-            raise NotImplementedError(f"odeint option {k}={options[k]!r} is not supported on the fused path")
+    # torchdiffeq's other fixed-grid options (FixedGridODESolver.__init__): `grid_constructor(func, y0, t)` returns the
+    # time grid instead of `step_size` (called in solver time: a decreasing span arrives negated; func and y0 are not
+    # known where the table is built and are passed as None), `perturb=True` evaluates a step's first stage at the next
+    # representable time after t0 and a stage taken at t1 itself at the one before t1 (right-hand sides with jumps on
+    # the grid), `interp` only matters for output times inside a step -- the reference asks for the end points only
+    grid_constructor = options.pop("grid_constructor", None)
+    perturb = bool(options.pop("perturb", False))
+    interp = options.pop("interp", "linear")
+    if interp not in ("linear", "cubic"):
+        raise ValueError(f"Unknown interpolation method {interp}")
     t_span = t_span.detach().to("cpu", torch.float32)
     sign = 1.0
     if bool(t_span[0] > t_span[-1]):
         sign = -1.0
         t_span = -t_span            # torchdiffeq solves decreasing spans in reversed time
-    grid = fixed_grid(t_span, step_size)
+    if grid_constructor is not None:
+        if step_size is not None:
+            raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
+        grid = torch.as_tensor(grid_constructor(None, None, t_span)).detach().to("cpu", torch.float32).reshape(-1)
+        if grid.numel() < 2 or grid[0] != t_span[0] or grid[-1] != t_span[-1]:
+            raise AssertionError("grid_constructor must return a grid that starts at t[0] and ends at t[-1]")
+        if not bool((grid[1:] > grid[:-1]).all()):
+            raise ValueError("grid_constructor must return strictly increasing times")
+    else:
+        grid = fixed_grid(t_span, step_size)
     if grid.numel() < 2:
         raise ValueError("time grid has fewer than two points")
     t0s, t1s = grid[:-1], grid[1:]
@@ -163,9 +179,9 @@ def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict]) -> Eval
     tau = torch.empty(n_steps, S, dtype=torch.float32)
     for i, c in enumerate(tab.c):
         if c is None:
-            tau[:, i] = t1s
+            tau[:, i] = torch.nextafter(t1s, t1s - 1) if perturb else t1s
         elif c == 0.0:
-            tau[:, i] = t0s
+            tau[:, i] = torch.nextafter(t0s, t0s + 1) if perturb else t0s
         else:
             tau[:, i] = t0s + dts * c
     cin = torch.zeros(n_steps, S, 8, dtype=torch.float32)

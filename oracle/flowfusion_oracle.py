@@ -423,11 +423,24 @@ def odeint_fixed(func: Callable, y0: Tuple[torch.Tensor, ...], t: torch.Tensor, 
         t = -t
         base = func
         func = lambda tt, yy: tuple(-f for f in base(-tt, yy))
-    grid = t if step_size is None else grid_from_step_size(t, step_size)
+    # FixedGridODESolver's other options: grid_constructor(func, y0, t) in place of step_size (solver time), and
+    # perturb: the step's first evaluation at nextafter(t0, +inf), an evaluation taken at t1 itself at nextafter(t1, -inf)
+    # (_PerturbFunc wraps the already reversed function, so the shift is applied in solver time)
+    if options.get("grid_constructor") is not None:
+        assert step_size is None, "step_size and grid_constructor are mutually exclusive arguments."
+        grid = options["grid_constructor"](func, y0, t)
+        assert grid[0] == t[0] and grid[-1] == t[-1]
+    else:
+        grid = t if step_size is None else grid_from_step_size(t, step_size)
     y = tuple(y0)
     for t0, t1 in zip(grid[:-1], grid[1:]):
         dt = t1 - t0
-        dy = step(func, t0, dt, t1, y)
+        f = func
+        if options.get("perturb"):
+            # the steppers hand `t0` / `t1` themselves to func for those two evaluations, computed times otherwise
+            f = lambda tt, yy, t0=t0, t1=t1: func(torch.nextafter(tt, tt + 1) if tt is t0 else
+                                                  (torch.nextafter(tt, tt - 1) if tt is t1 else tt), yy)
+        dy = step(f, t0, dt, t1, y)
         y = tuple(a + b for a, b in zip(y, dy))
     return y
 

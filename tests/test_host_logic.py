@@ -116,6 +116,53 @@ def test_plan_ode_rows():
         solvers.plan_ode(torch.tensor([0.0, 1.0]), "nope", None)
 
 
+def test_grid_constructor_and_perturb_options(built_library):
+    """torchdiffeq's other fixed-grid options (FixedGridODESolver): ``grid_constructor(func, y0, t)`` in place of
+    ``step_size`` (seen in solver time: a decreasing span arrives negated) and ``perturb=True`` (first stage one ulp
+    after t0, a stage taken at t1 one ulp before it) -- rows checked word by word, then the kernel's semantics on the
+    CPU against the oracle's restatement of the same options."""
+    seen = {}
+
+    def chebyshev_like(func, y0, t):
+        seen["t"] = t.clone()
+        u = torch.linspace(0, 1, 9, dtype=t.dtype) ** 2
+        g = t[0] + (t[-1] - t[0]) * u
+        g[-1] = t[-1]
+        return g
+
+    span = torch.tensor([1.0, 1e-3])
+    plan = solvers.plan_ode(span, "rk4", {"grid_constructor": chebyshev_like, "perturb": True})
+    assert seen["t"].tolist() == [-1.0, -0.0010000000474974513]            # the reversed span
+    g = chebyshev_like(None, None, -span)
+    assert plan.sign == -1.0 and plan.n_steps == 8
+    te = -plan.t_eval.view(8, 4)                                           # back to solver time
+    assert torch.equal(te[:, 0], torch.nextafter(g[:-1], g[:-1] + 1)) and torch.equal(te[:, 3], torch.nextafter(g[1:], g[1:] - 1))
+    assert torch.equal(te[:, 1], g[:-1] + (g[1:] - g[:-1]) * solvers._one_third)
+    torch.testing.assert_close(plan.cout.view(8, 4, 8)[:, 3, 0], (g[1:] - g[:-1]) * 0.125, rtol=0, atol=0)
+    plain = solvers.plan_ode(span, "midpoint", {"step_size": 0.25, "perturb": True})
+    assert torch.equal(-plain.t_eval.view(-1, 2)[:, 0], torch.nextafter(torch.tensor([-1.0, -0.75, -0.5, -0.25]), torch.tensor(0.0)))
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        solvers.plan_ode(span, "euler", {"step_size": 0.1, "grid_constructor": chebyshev_like})
+    with pytest.raises(AssertionError):
+        solvers.plan_ode(span, "euler", {"grid_constructor": lambda f, y, t: t * 0.5})
+    with pytest.raises(ValueError, match="interpolation"):
+        solvers.plan_ode(span, "euler", {"interp": "nope"})
+
+    torch.manual_seed(2)
+    sm = D.ScoreModel(D.MLP(5, 2, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+    so = O.ScoreOracle(O.mlp_params_from_state_dict(dict(sm.state_dict()), "model."), O.VE(dtype=torch.float64), no_sigma=False,
+                       dtype=torch.float64)
+    base, cond = torch.randn(12, 5), torch.randn(12, 2)
+    eps = float(sm.sde.epsilon)
+    for method in ("euler", "heun3", "rk4"):
+        opts = {"grid_constructor": chebyshev_like, "perturb": True}
+        table = sm._ode_table(torch.tensor([1.0, eps]), method, opts, MODE_STATE)
+        z = base * sm.sde.sigma_max
+        got, _ = _emulate_score(sm, z, table, MODE_STATE, cond)
+        ref = so.sample_ode_from_base(base.double(), cond.double(), method, opts)
+        assert max_rel(got, ref, floor=ref.abs().max().item()) < 3e-5, method
+
+
 def test_euler_maruyama_times():
     ts, dt = solvers.plan_euler_maruyama(1.0, torch.tensor(1e-3), 100)
     assert ts.numel() == 100 and ts[0] == 1.0
