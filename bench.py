@@ -245,6 +245,48 @@ def extra_configs(device):
     return out
 
 
+def streaming_helpers(device):
+    """The memory-bound kernels beside the fused integrator (csrc/ff_aux.hip: Runge-Kutta stage algebra of the module path,
+    error norms of an adaptive step, the counter-based prior draw) at solver-sized arrays (2^22 x 16 fp32): algorithmic
+    bytes / HIP-event time against the 8 TB/s HBM roofline, next to torch's own copy kernel on the same box."""
+    from flowfusion_amd import _native
+    B, D = 1 << 22, 16
+    n = B * D
+    x = torch.randn(B, D, device=device)
+    ks = [torch.randn(B, D, device=device) for _ in range(7)]
+    out = torch.empty_like(x)
+
+    def ms_of(fn, reps=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / reps
+
+    rows = []
+
+    def rec(kernel, nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"kernel": kernel, "ms": ms, "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                                "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes": nbytes}})
+
+    rec("torch copy_ (yardstick: 8 B per element)", 8 * n, ms_of(lambda: out.copy_(x)))
+    rec("ff_stage_combine, 4 terms + x (24 B per element)", 24 * n,
+        ms_of(lambda: _native.stage_combine(out, x, ks[:4], [0.1, 0.2, 0.3, 0.4], 1.0)))
+    rec("ff_stage_combine, 7 terms + x (36 B per element)", 36 * n,
+        ms_of(lambda: _native.stage_combine(out, x, ks, [0.1 * (i + 1) for i in range(7)], 1.0)))
+    rec("ff_scaled_rms, error norm of an adaptive step + finiteness check (16 B per element, one read-back)", 16 * n,
+        ms_of(lambda: _native.scaled_rms([(ks[1], None, x, ks[0])], 1e-5, 1e-5, check=ks[0])))
+    rec("ff_normal_fill (4 B per element written; Philox4x32-10 + Box-Muller)", 4 * n,
+        ms_of(lambda: _native.normal_fill(B, D, 1234, 0, device)))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,6 +462,7 @@ def main():
             if args.cpu_batch > 0:
                 out["split_precision_record"]["log_prob_rel_err"] = split_lp_err
             out["extra_configs"] = extra_configs(device)
+            out["streaming_helpers"] = streaming_helpers(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

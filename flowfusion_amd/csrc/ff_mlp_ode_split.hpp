@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #ifdef FF_SPLIT_STAMP_GAPS      // diagnostic: a stamp behind every MFMA of groups 0 and 1 of k-step 3
                         if constexpr (s == 3 && rt < 2) FF_STAMP();
 #endif
-#ifdef FF_SPLIT_UNITS_EVEN_ONLY   // diagnostic: the activation units run in k-steps 0, 2, 4, 6 only (wrong results)
-                        if constexpr (s % 2 == 1) return;
+#ifdef FF_SPLIT_UNITS_PARITY      // diagnostic: the activation units run in the k-steps of one parity only (wrong results)
+                        if constexpr (s % 2 != (FF_SPLIT_UNITS_PARITY)) return;
 #endif
                         if constexpr (s < NS - 1)       // the operands of the next k-step, out of the layer before
                             act_gap(std::integral_constant<int, 0>{}, std::integral_constant<int, G>{},
