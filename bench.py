@@ -106,7 +106,7 @@ def _record(name, units, unit, wall_s, kernel, kernel_ms, flop, note):
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS}, "dtype": "f32", **{k: v for k, v in note.items() if k != "launches"}}
 
 
-def split_precision_record(device, z, opts, steps, warmup, f32_x):
+def split_precision_record(device, z, opts, steps, warmup, f32_x, precision="bf16x3"):
     """The SAME workload as the headline loop on the opt-in split-precision kernels (precision="bf16x3": every fp32
     operand cut into three bf16 parts, six bf16 MFMAs per product term, fp32 accumulate -- fp32-class accuracy).  A
     second record beside the f32 line, never instead of it.  Two rooflines: the bf16 MFMA peak against the MFMA work
@@ -114,7 +114,8 @@ def split_precision_record(device, z, opts, steps, warmup, f32_x):
     the f32 line."""
     from flowfusion_amd import _native
     sm = build_model(device)
-    sm.precision = "bf16x3"
+    sm.precision = precision
+    parts, products = (3, 6) if precision == "bf16x3" else (2, 3)
     B = z.shape[0]
     for _ in range(warmup):
         x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
@@ -133,17 +134,19 @@ def split_precision_record(device, z, opts, steps, warmup, f32_x):
     # executed: 12 bf16 MFMAs (six products x two column blocks of 16 samples) per (16-row tile, 32-wide k-step) -- first
     # layer 16 tiles x 1 k-step, hidden 16 x 8 each, output 1 x 8 -- of 2 x 16 x 16 x 32 FLOP each, per 32 samples and
     # evaluation
-    mfma_per_eval = 12 * (16 * 1 + 3 * 16 * 8 + 8)
+    mfma_per_eval = 2 * products * (16 * 1 + 3 * 16 * 8 + 8)
     flop_exec = mfma_per_eval * 16384.0 * n_evals * (B / 32)
     err = float((x - f32_x).abs().max() / f32_x.abs().max())
     return {
         "metric": "samples/sec (whole node), 16-dim VP-SDE 100-step RK4", "value": B * steps / elapsed, "unit": "samples/s",
         "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-        "dtype": "bf16x3-split, f32 accumulate", "precision_option": "bf16x3 (opt-in; the default and the headline are f32)",
+        "dtype": f"{precision}-split, f32 accumulate", "precision_option": f"{precision} (opt-in; the default and the headline are f32)",
+        "arithmetic": ("three bf16 parts per operand by truncation (exact), six products per term" if parts == 3 else
+                       "two bf16 parts per operand by round-to-nearest (16 significand bits, unbiased), three products per term"),
         "kernel": _native.kernel_name(sm._net().plan(0)), "kernel_ms_avg": kms,
         "roofline": {"bound": "mfma", "achieved": flop_exec / (kms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": flop_exec / (kms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                     "flop_executed_per_launch": flop_exec, "note": "executed bf16 MFMA FLOPs (6 products per term) vs the dense bf16 peak"},
+                     "flop_executed_per_launch": flop_exec, "note": f"executed bf16 MFMA FLOPs ({products} products per term) vs the dense bf16 peak"},
         "fp32_equivalent": {"achieved": flop_alg / (kms * 1e-3) / 1e12, "unit": "TFLOP/s", "flop_per_launch": flop_alg,
                             "vs_fp32_mfma_peak": flop_alg / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
         "max_abs_diff_vs_f32_kernel_over_max_abs": err,
@@ -446,21 +449,40 @@ def main():
             lp = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
             lp_ref = so.log_prob(xq, None, "rk4", opts, "hutch", sm.e.cpu())
             out["log_prob_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+            split_lp_err = {}
             if args.extras:     # the same check on the split-precision kernels (same points, same probe)
-                sm.precision = "bf16x3"
-                torch.manual_seed(99)
-                assert torch.equal(torch.randn(128, DIM) * 0.9, xq)
-                lps = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
-                split_lp_err = float(((lps - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+                for prec in ("bf16x3", "bf16x2"):
+                    sm.precision = prec
+                    torch.manual_seed(99)
+                    assert torch.equal(torch.randn(128, DIM) * 0.9, xq)
+                    lps = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
+                    split_lp_err[prec] = float(((lps - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
                 sm.precision = "f32"
             sm.hutch = False
             _, _, cb1 = cpu_baseline(sm, 2048, opts, budget_s=10.0, threads=1)
             out["cpu_baseline_1thread"] = cb1
             torch.set_num_threads(usable_cores())
         if args.extras and world == 1:
-            out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x)
+            out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x3")
+            out["split_precision_record_bf16x2"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x2")
             if args.cpu_batch > 0:
-                out["split_precision_record"]["log_prob_rel_err"] = split_lp_err
+                out["split_precision_record"]["log_prob_rel_err"] = split_lp_err["bf16x3"]
+                out["split_precision_record_bf16x2"]["log_prob_rel_err"] = split_lp_err["bf16x2"]
+                # state error of each arithmetic against the float64 oracle on the CPU sample's base points
+                from oracle import flowfusion_oracle as O64
+                so64 = O64.ScoreOracle(O64.mlp_params_from_state_dict(sd, "model."), O64.VP(dtype=torch.float64), no_sigma=True,
+                                       dtype=torch.float64)
+                zs = zc[:256]
+                r64 = so64.sample_ode_from_base(zs.double(), None, "rk4", opts)
+                for prec, key in (("f32", None), ("bf16x3", "split_precision_record"), ("bf16x2", "split_precision_record_bf16x2")):
+                    sm.precision = prec
+                    xg, _ = sm.sample_ode_from_base(zs.to(device), method="rk4", options=opts)
+                    e64 = float((xg.cpu().double() - r64).abs().max() / r64.abs().max())
+                    if key is None:
+                        out["parity_vs_cpu_oracle"]["max_abs_err_over_max_abs_vs_float64_oracle"] = e64
+                    else:
+                        out[key]["max_abs_err_over_max_abs_vs_float64_oracle"] = e64
+                sm.precision = "f32"
             out["extra_configs"] = extra_configs(device)
             out["streaming_helpers"] = streaming_helpers(device)
         print(json.dumps(out), flush=True)

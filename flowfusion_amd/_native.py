@@ -24,8 +24,8 @@ MODE_HUTCH = 1
 MODE_EXACT = 2
 
 # FF_PREC_* of include/flowfusion_amd.h
-PREC_F32, PREC_BF16X3 = 0, 1
-PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3}
+PREC_F32, PREC_BF16X3, PREC_BF16X2 = 0, 1, 2
+PRECISIONS = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16x2": PREC_BF16X2}
 
 # FF_ACT_* of include/flowfusion_amd.h
 ACT_SILU, ACT_TANH, ACT_SIGMOID, ACT_RELU, ACT_LEAKY_RELU, ACT_ELU, ACT_SOFTPLUS, ACT_GELU, ACT_GELU_TANH = range(9)
@@ -181,9 +181,10 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
     arr = (ctypes.c_int * len(hidden))(*hidden)
     prm = (ctypes.c_float * 2)(float(act[1]), float(act[2]))
     rc = lib().ff_mlp_plan_prec(dim, cond_dim, len(hidden), arr, mode, int(act[0]), prm, int(precision), ctypes.byref(p))
-    if rc == FF_ERR_UNSUPPORTED and precision == PREC_BF16X3:
+    if rc == FF_ERR_UNSUPPORTED and precision in (PREC_BF16X3, PREC_BF16X2):
+        name = "bf16x3" if precision == PREC_BF16X3 else "bf16x2"
         raise NotImplementedError(
-            f"precision='bf16x3' has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
+            f"precision='{name}' (one of the split-precision options 'bf16x3' / 'bf16x2') has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
             f"activation={act[0]}: the split-precision family covers SiLU networks of 1-6 hidden layers up to 256 wide, "
             "dim <= 16, cond_dim <= 16, state-only and Hutchinson solves on a fixed grid; use precision='f32'")
     if rc == FF_ERR_UNSUPPORTED:

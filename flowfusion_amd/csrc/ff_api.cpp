@@ -14,7 +14,7 @@ static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
 
 static thread_local int t_last_hip_error = 0;
 
-extern "C" const char* ff_version(void) { return "flowfusion_amd 0.2 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 split on 32x32x16 bf16; in-register layer chaining)"; }
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.2 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 / bf16x2 split on 16x16x32 bf16; in-register layer chaining)"; }
 
 extern "C" int ff_kernel_count(void) { return ff::g_n_kernels + ff::g_n_split_kernels; }
 
@@ -38,10 +38,12 @@ static int tangents_of_mode(int mode, int dim, int tile, int* n_tangent, int* un
     }
 }
 
-// FF_PREC_BF16X3: the split-precision family (ff_mlp_ode_split.hpp) -- SiLU, width <= 32 nt, dim <= 16,
+static inline int split_parts(int precision) { return precision == FF_PREC_BF16X2 ? 2 : 3; }
+
+// FF_PREC_BF16X3 / FF_PREC_BF16X2: the split-precision family (ff_mlp_ode_split.hpp) -- SiLU, width <= 256, dim <= 16,
 // cond_dim <= 16, state-only or Hutchinson, the number of hidden layers compiled in
 static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode, int activation,
-                      ff_mlp_plan_t* plan)
+                      int precision, ff_mlp_plan_t* plan)
 {
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
@@ -57,7 +59,7 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
     int best = -1;
     for (int i = 0; i < ff::g_n_split_kernels; ++i) {
         const ff::SplitKernelEntry& k = ff::g_split_kernels[i];
-        if (k.n_hidden == n_hidden && k.tangents == need_t) best = i;
+        if (k.n_hidden == n_hidden && k.tangents == need_t && k.parts == split_parts(precision)) best = i;
     }
     if (best < 0) return FF_ERR_UNSUPPORTED;
     memset(plan, 0, sizeof(*plan));
@@ -70,7 +72,7 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
     plan->kernel_id = best;
     plan->tile = 32;
     plan->activation = FF_ACT_SILU;
-    plan->precision = FF_PREC_BF16X3;
+    plan->precision = precision;
     return FF_OK;
 }
 
@@ -89,8 +91,8 @@ extern "C" int ff_mlp_plan_act(int dim, int cond_dim, int n_hidden, const int* h
 extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* hidden_widths, int mode,
                                 int activation, const float* act_param, int precision, ff_mlp_plan_t* plan)
 {
-    if (precision != FF_PREC_F32 && precision != FF_PREC_BF16X3) return FF_ERR_BADARG;
-    if (precision == FF_PREC_BF16X3) return plan_split(dim, cond_dim, n_hidden, hidden_widths, mode, activation, plan);
+    if (precision != FF_PREC_F32 && precision != FF_PREC_BF16X3 && precision != FF_PREC_BF16X2) return FF_ERR_BADARG;
+    if (precision != FF_PREC_F32) return plan_split(dim, cond_dim, n_hidden, hidden_widths, mode, activation, precision, plan);
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
     if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
@@ -136,9 +138,11 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
 
 static bool plan_ok_split(const ff_mlp_plan_t* p)
 {
-    if (!p || p->precision != FF_PREC_BF16X3 || p->kernel_id < 0 || p->kernel_id >= ff::g_n_split_kernels) return false;
+    if (!p || (p->precision != FF_PREC_BF16X3 && p->precision != FF_PREC_BF16X2) || p->kernel_id < 0 ||
+        p->kernel_id >= ff::g_n_split_kernels)
+        return false;
     const ff::SplitKernelEntry& k = ff::g_split_kernels[p->kernel_id];
-    return p->width == ff::split::kWidth && p->tile == 32 && p->dregs == 8 && p->cregs == (p->cond_dim > 0 ? 8 : 0) &&
+    return k.parts == split_parts(p->precision) && p->width == ff::split::kWidth && p->tile == 32 && p->dregs == 8 && p->cregs == (p->cond_dim > 0 ? 8 : 0) &&
            p->n_hidden == k.n_hidden && p->activation == FF_ACT_SILU && p->dim >= 1 && p->dim <= 16 &&
            p->cond_dim >= 0 && p->cond_dim <= 16;
 }
@@ -169,7 +173,7 @@ extern "C" const char* ff_plan_kernel_name(const ff_mlp_plan_t* plan)
 extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
 {
     if (plan_ok_split(plan)) {
-        return ff::split::total_words(plan->n_hidden);
+        return ff::split::total_words(plan->n_hidden, split_parts(plan->precision));
     }
     if (!plan_ok(plan)) return 0;
     return plan_layout(plan).total_floats;
@@ -187,25 +191,44 @@ static inline uint16_t bf16_top(float v, float* rest)
     return (uint16_t)(t >> 16);
 }
 
-// FF_PREC_BF16X3 packing: the fragment stream of ff_split_layout.h followed by the fp32 biases
+// round-to-nearest-even bf16 of v (weights are finite), and what is left
+static inline uint16_t bf16_rne(float v, float* rest)
+{
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    const uint32_t t = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    float tf;
+    memcpy(&tf, &t, 4);
+    *rest = v - tf;
+    return (uint16_t)(t >> 16);
+}
+
+// FF_PREC_BF16X3 / BF16X2 packing: the fragment stream of ff_split_layout.h followed by the fp32 biases.  Three parts:
+// truncation (hi + mid + lo = the fp32 weight exactly); two parts: round to nearest (hi + mid = the weight to 16 bits)
 static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
                        const int* hidden_widths, int in_features0, int x_col0, int c_col0, float* out)
 {
     namespace sp = ff::split;
     const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden;
+    const int NP = split_parts(plan->precision);
     uint32_t* words = (uint32_t*)out;
-    memset(out, 0, sp::total_words(NH) * 4);
+    memset(out, 0, sp::total_words(NH, NP) * 4);
     size_t group = 0;                                  // running group index in the stream
     // one group: fragments [hi, mid, lo] of 16-row tile rt; element (quad q, j) multiplies input column col(q, j)
     auto put_group = [&](const float* Wl, int rows, int ld, int rt, auto col) {
-        uint32_t* g = words + group * (sp::kGroupFrags * sp::kFragBytes / 4);
+        uint32_t* g = words + group * (NP * sp::kFragBytes / 4);
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
                 const int row = 16 * rt + (lane & 15), c = col(lane >> 4, j);
                 const float v = (row < rows && c >= 0) ? Wl[(size_t)row * ld + c] : 0.f;
                 float r1, r2, r3;
-                const uint16_t part[3] = {bf16_top(v, &r1), bf16_top(r1, &r2), bf16_top(r2, &r3)};
-                for (int p = 0; p < 3; ++p) {
+                uint16_t part[3];
+                if (NP == 3) {
+                    part[0] = bf16_top(v, &r1); part[1] = bf16_top(r1, &r2); part[2] = bf16_top(r2, &r3);
+                } else {
+                    part[0] = bf16_rne(v, &r1); part[1] = bf16_rne(r1, &r2); part[2] = 0;
+                }
+                for (int p = 0; p < NP; ++p) {
                     uint32_t& w = g[p * 256 + lane * 4 + (j >> 1)];
                     w = (j & 1) ? ((w & 0x0000FFFFu) | ((uint32_t)part[p] << 16)) : ((w & 0xFFFF0000u) | part[p]);
                 }
@@ -227,7 +250,7 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
                     const int kk = sp::kidx(s, q, j);
                     return kk < win ? kk : -1;
                 });
-        float* bo = out + sp::stream_words(NH) + (size_t)(l - 1) * H;
+        float* bo = out + sp::stream_words(NH, NP) + (size_t)(l - 1) * H;
         for (int row = 0; row < wout; ++row) bo[row] = b[l][row];
     }
     // output layer: one row tile (the state's dimensions), all k-steps
@@ -238,7 +261,7 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
                 const int kk = sp::kidx(s, q, j);
                 return kk < win ? kk : -1;
             });
-        float* bo = out + sp::stream_words(NH) + (size_t)(NH - 1) * H;
+        float* bo = out + sp::stream_words(NH, NP) + (size_t)(NH - 1) * H;
         for (int row = 0; row < D; ++row) bo[row] = b[NH][row];
     }
     return group == (size_t)sp::granules_per_eval(NH) * sp::kGranuleGroups ? FF_OK : FF_ERR_BADARG;
@@ -353,11 +376,11 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.n_tangent = k.tangents ? 1 : 0;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
-    ka.wpack_floats = (int)ff::split::total_words(k.n_hidden);
+    ka.wpack_floats = (int)ff::split::total_words(k.n_hidden, k.parts);
     const long long spw = k.tangents ? 64 : 128;
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
-    const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden).total;
+    const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden, k.parts).total;
     const int herr = k.launch(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
     if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
     return FF_OK;

@@ -69,31 +69,35 @@ __device__ __forceinline__ f32x4 mm(u32x4 a, u32x4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// one group: the six products of (w_hi, w_mid, w_lo) x (x_hi, x_mid, x_lo) that matter, for both column blocks
-// (interleaved: consecutive MFMAs never depend on each other)
-__device__ __forceinline__ void group12(f32x4 (&acc)[2], const u32x4 (&w)[3], const u32x4 (&b)[2][3])
-{
-    acc[0] = mm(w[0], b[0][0], acc[0]); acc[1] = mm(w[0], b[1][0], acc[1]);
-    acc[0] = mm(w[0], b[0][1], acc[0]); acc[1] = mm(w[0], b[1][1], acc[1]);
-    acc[0] = mm(w[1], b[0][0], acc[0]); acc[1] = mm(w[1], b[1][0], acc[1]);
-    acc[0] = mm(w[0], b[0][2], acc[0]); acc[1] = mm(w[0], b[1][2], acc[1]);
-    acc[0] = mm(w[1], b[0][1], acc[0]); acc[1] = mm(w[1], b[1][1], acc[1]);
-    acc[0] = mm(w[2], b[0][0], acc[0]); acc[1] = mm(w[2], b[1][0], acc[1]);
-}
 // top halves of (a, b) -> one register of two bf16 (a in the low half): truncation split
 __device__ __forceinline__ unsigned pack_hi(float a, float b)
 {
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
 }
 __device__ __forceinline__ float top(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u); }
-// two fp32 values -> word j of the three fragments
-__device__ __forceinline__ void split2(float v0, float v1, u32x4 (&o)[3], int j)
+// (a, b) rounded to nearest-even bf16, a in the low half: one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_rne(float a, float b)
 {
-    const float m0 = v0 - top(v0), m1 = v1 - top(v1);
-    const float l0 = m0 - top(m0), l1 = m1 - top(m1);
-    o[0][j] = pack_hi(v0, v1);
-    o[1][j] = pack_hi(m0, m1);
-    o[2][j] = pack_hi(l0, l1);
+    return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b});
+}
+__device__ __forceinline__ float lo_half(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_half(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+// two fp32 values -> word j of the NP fragments: three parts by truncation (exact), two by round-to-nearest
+template <int NP>
+__device__ __forceinline__ void split2(float v0, float v1, u32x4 (&o)[NP], int j)
+{
+    if constexpr (NP == 3) {
+        const float m0 = v0 - top(v0), m1 = v1 - top(v1);
+        const float l0 = m0 - top(m0), l1 = m1 - top(m1);
+        o[0][j] = pack_hi(v0, v1);
+        o[1][j] = pack_hi(m0, m1);
+        o[2][j] = pack_hi(l0, l1);
+    } else {
+        const unsigned h = pack_rne(v0, v1);
+        o[0][j] = h;
+        o[1][j] = pack_rne(v0 - lo_half(h), v1 - hi_half(h));
+    }
 }
 // value of the even neighbour lane (the value column of a (value, tangent) column pair): DPP quad_perm [0, 0, 2, 2]
 __device__ __forceinline__ float from_value_lane(float v)
@@ -101,13 +105,12 @@ __device__ __forceinline__ float from_value_lane(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xA0, 0xF, 0xF, true));
 }
 
-// Activation + split of one UNIT = two pre-activations -> one word of the three fragments, cut into MICRO-OPS of at
+// Activation + split of one UNIT = two pre-activations -> one word of the NP fragments, cut into MICRO-OPS of at
 // most two plain VALU instructions or one transcendental: what fits the 8 cycles of vector issue a 16-cycle MFMA
 // leaves free (MI355X_MICROARCH.md, issue costs).  Every micro-op is pinned behind one particular MFMA (a GAP; plan
 // below): left to the list scheduler the same instructions clump -- four or five behind one MFMA, none behind the next
-// six -- and every instruction past the free 8 cycles delays the matrix pipe by its full issue time.  Value columns:
-// SiLU(a).  Tangent columns (forward-mode derivative through the same weights): a' * SiLU'(a of the sample's value
-// column), SiLU'(a) = s + a s (1 - s).
+// six.  Value columns: SiLU(a).  Tangent columns (forward-mode derivative through the same weights): a' * SiLU'(a of
+// the sample's value column), SiLU'(a) = s + a s (1 - s).
 #ifndef FF_SPLIT_AHEAD
 #define FF_SPLIT_AHEAD 1
 #endif
@@ -119,20 +122,22 @@ struct UnitState {
 enum MicroOp {
     M_LOAD, M_SCALE, M_EXP0, M_EXP1, M_ADD1, M_RCP0, M_RCP1, M_VALUE,
     M_TV_H, M_TV_OMS, M_TV_SLOPE, M_TV_DPP, M_TV_MUL, M_TV_SEL,           // tangent kernels: in place of M_VALUE
-    M_TOPH, M_RESM, M_PACKH, M_PACKM, M_RESL, M_PACKL
+    M_TOPH, M_RESM, M_PACKH, M_PACKM, M_RESL, M_PACKL,                    // three parts by truncation
+    M_RHI, M_RRES, M_RMID                                                 // two parts by round-to-nearest
 };
-FF_HD constexpr int micro_count(bool tangents) { return tangents ? 19 : 14; }
-FF_HD constexpr int micro_op(bool tangents, int j)
+FF_HD constexpr int micro_count(bool tangents, int parts) { return (tangents ? 13 : 8) + (parts == 3 ? 6 : 3); }
+FF_HD constexpr int micro_op(bool tangents, int parts, int j)
 {
     if (j < 7) return j;                                   // M_LOAD .. M_RCP1
-    if (!tangents) return j == 7 ? M_VALUE : M_TOPH + (j - 8);
-    return j < 13 ? M_TV_H + (j - 7) : M_TOPH + (j - 13);
+    const int nv = tangents ? 6 : 1;                       // micro-ops that form the activation value
+    if (j < 7 + nv) return tangents ? M_TV_H + (j - 7) : M_VALUE;
+    return (parts == 3 ? M_TOPH : M_RHI) + (j - 7 - nv);
 }
-template <bool TANGENTS, int J>
-__device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u, u32x4 (&frag)[3], int word, bool is_tangent)
+template <bool TANGENTS, int NP, int J>
+__device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u, u32x4 (&frag)[NP], int word, bool is_tangent)
 {
     constexpr float NLOG2E = -1.44269504088896340736f;
-    constexpr int OP = micro_op(TANGENTS, J);
+    constexpr int OP = micro_op(TANGENTS, NP, J);
 #ifdef FF_SPLIT_SKIP_OPS        // timing experiments only: bit OP set = that micro-op is left out (wrong results)
     if constexpr (((FF_SPLIT_SKIP_OPS) >> OP) & 1) return;
 #endif
@@ -190,56 +195,83 @@ __device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u,
     } else if constexpr (OP == M_RESL) {
         u.a0 = u.t0 - u.a0;
         u.a1 = u.t1 - u.a1;
+    } else if constexpr (OP == M_PACKL) {
+        frag[NP - 1][word] = pack_hi(u.a0, u.a1);
+    } else if constexpr (OP == M_RHI) {        // two-way split, round to nearest: hi = bf16(a), mid = bf16(a - hi)
+        const unsigned h = pack_rne(u.a0, u.a1);
+        frag[0][word] = h;
+        u.t0 = lo_half(h);
+        u.t1 = hi_half(h);
+    } else if constexpr (OP == M_RRES) {
+        u.t0 = u.a0 - u.t0;
+        u.t1 = u.a1 - u.t1;
     } else {
-        frag[2][word] = pack_hi(u.a0, u.a1);
+        frag[NP - 1][word] = pack_rne(u.t0, u.t1);
     }
 }
 
-// GAP PLAN of a span of 16 groups = 192 MFMAs (one k-step of a hidden layer, or the whole first layer): which micro-op
-// of which of the 8 units (a k-step's operands: 2 column blocks x 4 words) sits behind MFMA g of the span.  Built
-// greedily: a unit's micro-ops are at least two gaps apart (nothing waits on the instruction before it), a gap holds one
-// micro-op, and the gaps that carry an LDS-DMA (the even gaps of the groups that open a granule) hold none.  Units of
-// span kind 1 read row tiles 0 and 1 of the span's OWN output, complete after groups 0 and 1: they start at gap 24.
-constexpr int kSpanGaps = 16 * 12;
+// GAP PLAN of a span of 16 groups (one k-step of a hidden layer, or the whole first layer; 12 MFMAs per group with three
+// parts, 6 with two): which micro-ops of which of the 8 units (a k-step's operands: 2 column blocks x 4 words) sit
+// behind MFMA g of the span.  Built greedily: a unit's micro-ops are at least two gaps apart (nothing waits on the
+// instruction before it), the gaps that carry an LDS-DMA hold none, and a gap holds as few micro-ops as the span's room
+// allows (one with three parts; up to two with two parts, whose k-steps are half as long).  Units of span kind 1 read
+// row tiles 0 and 1 of the span's OWN output, complete after groups 0 and 1: they start behind group 1.
+constexpr int kMaxSpanGaps = 16 * 12, kMaxPerGap = 3;
 #ifndef FF_SPLIT_SPACING
 #define FF_SPLIT_SPACING 2
 #endif
 constexpr int kMicroSpacing = FF_SPLIT_SPACING;      // gaps between consecutive micro-ops of a unit
+FF_HD constexpr int gaps_per_group(int parts) { return 2 * products_of(parts); }
+// gap i of a group that opens a granule issues one of the wavefront's 2 * parts LDS-DMAs
+FF_HD constexpr bool dma_gap(int parts, int i) { return parts == 3 ? (i % 2 == 0) : (i < 4); }
+FF_HD constexpr int dma_index(int parts, int i) { return parts == 3 ? i / 2 : i; }
+// gap i of a group reads fragment `part` of the group kAhead on from LDS (-1: none)
+FF_HD constexpr int read_part(int parts, int i) { return parts == 3 ? (i % 4 == 1 ? i / 4 : -1) : (i == 1 ? 0 : (i == 4 ? 1 : -1)); }
 struct GapPlan {
-    signed char unit[kSpanGaps];
-    signed char micro[kSpanGaps];
+    signed char n[kMaxSpanGaps];
+    signed char unit[kMaxSpanGaps][kMaxPerGap];
+    signed char micro[kMaxSpanGaps][kMaxPerGap];
     bool ok;
 };
-FF_HD constexpr GapPlan make_gap_plan(bool tangents, int first_gap)
+FF_HD constexpr GapPlan make_gap_plan(bool tangents, int parts, int first_gap)
 {
     GapPlan p{};
-    bool dma[kSpanGaps] = {};
-    for (int g = 0; g < kSpanGaps; ++g) {
-        p.unit[g] = -1;
-        p.micro[g] = -1;
-        dma[g] = ((g / 12) % kGranuleGroups == 0) && ((g % 12) % 2 == 0);
+    const int per = gaps_per_group(parts), span = 16 * per, nm = micro_count(tangents, parts);
+    bool dma[kMaxSpanGaps] = {};
+    int room = 0;
+    for (int g = 0; g < span; ++g) {
+        dma[g] = ((g / per) % kGranuleGroups == 0) && dma_gap(parts, g % per);
+        room += (g >= first_gap && !dma[g]) ? 1 : 0;
     }
-    p.ok = true;
-    for (int u = 0; u < 8; ++u) {
-        int g = first_gap;
-        for (int j = 0; j < micro_count(tangents); ++j) {
-            while (g < kSpanGaps && (dma[g] || p.unit[g] >= 0)) ++g;
-            if (g >= kSpanGaps) {
-                p.ok = false;
-                return p;
+    const int cap = (8 * nm + room - 1) / room;
+    p.ok = cap <= kMaxPerGap;
+    for (int cap_now = cap; p.ok; ++cap_now) {           // (the spacing rule can strand a unit at the span's end: allow one more per gap)
+        for (int g = 0; g < kMaxSpanGaps; ++g) p.n[g] = 0;
+        bool fits = true;
+        for (int u = 0; u < 8 && fits; ++u) {
+            int g = first_gap;
+            for (int j = 0; j < nm && fits; ++j) {
+                while (g < span && (dma[g] || p.n[g] >= cap_now)) ++g;
+                if (g >= span) {
+                    fits = false;
+                    break;
+                }
+                p.unit[g][p.n[g]] = (signed char)u;
+                p.micro[g][p.n[g]] = (signed char)j;
+                ++p.n[g];
+                g += kMicroSpacing;
             }
-            p.unit[g] = (signed char)u;
-            p.micro[g] = (signed char)j;
-            g += kMicroSpacing;
         }
+        if (fits) break;
+        if (cap_now >= kMaxPerGap) p.ok = false;
     }
     return p;
 }
-template <bool TANGENTS>
+template <bool TANGENTS, int NP>
 struct GapPlans {
-    static constexpr GapPlan k0 = make_gap_plan(TANGENTS, 0);
-    static constexpr GapPlan k1 = make_gap_plan(TANGENTS, 24);
-    static_assert(k0.ok && k1.ok, "the activation micro-ops of a k-step do not fit its 192 gaps");
+    static constexpr GapPlan k0 = make_gap_plan(TANGENTS, NP, 0);
+    static constexpr GapPlan k1 = make_gap_plan(TANGENTS, NP, 2 * gaps_per_group(NP));
+    static_assert(k0.ok && k1.ok, "the activation micro-ops of a k-step do not fit behind its MFMAs");
 };
 
 // LDS-DMA of one fragment: 64 lanes x 16 bytes from `g` (wave-uniform) + lane * 16 to LDS byte `lds_byte` + lane * 16.
@@ -252,13 +284,16 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
 // straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
 // accumulator registers at every control-flow join).
-template <int NH, bool TANGENTS>
+template <int NH, bool TANGENTS, int NP = 3>
 __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
+    static_assert(NP == 2 || NP == 3, "two (round-to-nearest) or three (truncation) bf16 parts per operand");
     constexpr int NR = kRowTiles;                      // 16 row tiles of 16 rows: width 256
     constexpr int NS = kKSteps;                        // 8 k-steps of 32 features
     constexpr int H = 16 * NR;
-    constexpr int GB = kGranuleBytes;                  // 24 KiB
+    constexpr int GB = granule_bytes(NP);              // 24 KiB (three parts) / 16 KiB (two)
+    constexpr int GG = gaps_per_group(NP);             // MFMAs of a group: 12 / 6
+    constexpr int NDMA = 2 * NP;                       // fragments of a granule this wavefront fetches: 6 / 4
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -268,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     const int col = lane & 15;                         // column within a column block
     const int lane16 = lane * 16;
     const int D = args.dim, C = args.cond_dim;
-    const LdsMap M = lds_map(H, NH);
+    const LdsMap M = lds_map(H, NH, NP);
 
     // ---- column roles: this lane serves one column of each of the two column blocks ---------------------------------
     const long long wave = (long long)blockIdx.x * 4 + wv;
@@ -290,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     // ---- state / probe / conditional: register i of column block cb holds dimension 4 qd + i -------------------------
     f32x4* const ks = (f32x4*)(lds + M.slots) + threadIdx.x;          // slot s, column block cb: ks[(s * 2 + cb) * 256]
     float ee[2] = {0.f, 0.f};                          // tangent lanes: e.e restricted to this lane's dimensions
-    u32x4 yf[2][3];                                    // B fragments of the first layer: words 0,1 = state, 2,3 = conditional
+    u32x4 yf[2][NP];                                   // B fragments of the first layer: words 0,1 = state, 2,3 = conditional
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, cv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -316,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         // the state x lives in LDS (slot kSlots + 1; slot kSlots parks the stage input y): it is touched twice per
         // evaluation, and 8 more live registers would spill inside the loop
         ks[((kSlots + 1) * 2 + cb) * 256] = xv;
-        split2(cv[0], cv[1], yf[cb], 2);
-        split2(cv[2], cv[3], yf[cb], 3);
+        split2<NP>(cv[0], cv[1], yf[cb], 2);
+        split2<NP>(cv[2], cv[3], yf[cb], 3);
     }
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
@@ -325,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         for (int cb = 0; cb < 2; ++cb) ks[(s * 2 + cb) * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
-        const float* bsrc = args.wpack + (size_t)stream_words(NH);
+        const float* bsrc = args.wpack + (size_t)stream_words(NH, NP);
         const int nb = (NH - 1) * H + 16;
         for (int i = threadIdx.x; i < nb; i += 256) ((float*)(lds + M.hbias))[i] = bsrc[i];
     }
@@ -353,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     const long long wbytes = (long long)granules_per_eval(NH) * GB;
     long long dpos = 0;                                // byte position in the stream of the NEXT granule to fetch
     unsigned rbuf = 0;                                 // LDS byte offset of the buffer the current granule is read from
-    const int my_frag = wv * 6 * 1024;                 // this wavefront's quarter of a granule
+    const int my_frag = wv * NDMA * 1024;              // this wavefront's quarter of a granule
     auto fetch_c1 = [&](int e) __attribute__((always_inline)) {      // c1 of evaluation e -> its LDS buffer (every wavefront issues
         const int ee_ = e < args.n_evals ? e : 0;                      // the same 1 KiB copy: equal VMEM counts keep the counted waits uniform)
         dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32), lane16);
@@ -361,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     fetch_c1(0);
     for (int g = 0; g < 2; ++g) {                      // granules 0 and 1 into buffers 0 and 1
 #pragma unroll
-        for (int f = 0; f < 6; ++f) dma_fragment(g * GB + my_frag + f * 1024, wbase + dpos + my_frag + f * 1024, lane16);
+        for (int f = 0; f < NDMA; ++f) dma_fragment(g * GB + my_frag + f * 1024, wbase + dpos + my_frag + f * 1024, lane16);
         dpos += GB;
         if (dpos >= wbytes) dpos = 0;
     }
@@ -384,20 +419,21 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 
     // weight fragments of the current group (wq[0]) and of the kAhead groups after it, read from LDS kAhead groups
     // ahead (one group = 192 cycles is enough: distances 2 and 3 measured the same to 0.1 %)
-    u32x4 wq[kAhead + 1][3];
+    u32x4 wq[kAhead + 1][NP];
     int wa = lane16;                                   // LDS address of this lane's 16 bytes of fragment 0 of the granule
     int wa_next = lane16;
 #pragma unroll
     for (int a = 0; a < kAhead; ++a)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wq[a][p] = *(const u32x4*)(lds + wa + (a * 3 + p) * 1024);
+        for (int p = 0; p < NP; ++p) wq[a][p] = *(const u32x4*)(lds + wa + (a * NP + p) * 1024);
 
-    // ONE GROUP: 12 MFMAs = six products x two column blocks, in an order where consecutive MFMAs never depend on each
-    // other, each followed by what is pinned to its gap -- one fragment read of the next group (gaps 1, 5, 9), in the
-    // group that opens a granule one LDS-DMA of granule + 2 (even gaps), and `fill(gap)`, the caller's activation
-    // micro-op -- and a full scheduling barrier, so that the instruction stream is the one written here.  GQ = the
+    // ONE GROUP: the products of (w_hi, w_mid[, w_lo]) x (x_hi, x_mid[, x_lo]) that matter -- hh hm mh hl mm lh with
+    // three parts (dropped terms <= 2^-24 relative), hh hm mh with two -- for both column blocks, in an order where
+    // consecutive MFMAs never depend on each other, each followed by what is pinned to its gap: a fragment read of the
+    // next group, in the group that opens a granule an LDS-DMA of granule + 2, and `fill(gap)`, the caller's activation
+    // micro-ops -- and a full scheduling barrier, so that the instruction stream is the one written here.  GQ = the
     // group's index in its granule.
-    auto group = [&](auto gq, f32x4 (&acc)[2], const u32x4 (&b)[2][3], auto&& fill) __attribute__((always_inline)) {
+    auto group = [&](auto gq, f32x4 (&acc)[2], const u32x4 (&b)[2][NP], auto&& fill) __attribute__((always_inline)) {
         constexpr int GQ = decltype(gq)::value;
         const unsigned char* dsrc = nullptr;
         unsigned ddst = 0;
@@ -414,9 +450,10 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if (dpos >= wbytes) dpos = 0;
         }
         if constexpr (GQ == kGranuleGroups - kAhead) {
-            // everything but the six DMAs issued in this granule has landed, and this wavefront's reads of the current
+            // everything but the NDMA DMAs issued in this granule has landed, and this wavefront's reads of the current
             // buffer have returned: after the barrier the next granule is visible to all and the previous buffer is free
-            asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
 #ifndef FF_SPLIT_NOBARRIER       // timing experiment only (with FF_SPLIT_NODMA)
             __builtin_amdgcn_s_barrier();
 #endif
@@ -424,23 +461,25 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if (rbuf >= 3 * GB) rbuf = 0;
             wa_next = lane16 + rbuf;
         }
-        sfor<12>([&](auto ii) {
+        sfor<GG>([&](auto ii) {
             constexpr int I = decltype(ii)::value;
             constexpr int cb = I & 1, pr = I >> 1;
             constexpr int wp = (pr == 2 || pr == 4) ? 1 : (pr == 5 ? 2 : 0);        // hh hm mh hl mm lh
             constexpr int bp = (pr == 1 || pr == 4) ? 1 : (pr == 3 ? 2 : 0);
             acc[cb] = mm(wq[0][wp], b[cb][bp], acc[cb]);
+            constexpr int part = read_part(NP, I);
 #ifdef FF_SPLIT_NOWREAD          // timing experiment only: one group's fragments serve the whole granule (wrong results)
-            if constexpr (I % 4 == 1 && GQ == 0) {
+            if constexpr (part >= 0 && GQ == 0) {
 #else
-            if constexpr (I % 4 == 1) {
+            if constexpr (part >= 0) {
 #endif
-                constexpr int part = I / 4, T = GQ + kAhead;            // fragments of the group kAhead groups on
-                if constexpr (T >= kGranuleGroups) wq[kAhead][part] = *(const u32x4*)(lds + wa_next + ((T - kGranuleGroups) * 3 + part) * 1024);
-                else wq[kAhead][part] = *(const u32x4*)(lds + wa + (T * 3 + part) * 1024);
+                constexpr int T = GQ + kAhead;                          // fragments of the group kAhead groups on
+                if constexpr (T >= kGranuleGroups) wq[kAhead][part] = *(const u32x4*)(lds + wa_next + ((T - kGranuleGroups) * NP + part) * 1024);
+                else wq[kAhead][part] = *(const u32x4*)(lds + wa + (T * NP + part) * 1024);
             }
 #ifndef FF_SPLIT_NODMA           // timing experiment only: never refresh the weight buffers (wrong results)
-            if constexpr (GQ == 0 && (I & 1) == 0) dma_fragment(ddst + (I / 2) * 1024, dsrc + (I / 2) * 1024, lane16);
+            if constexpr (GQ == 0 && dma_gap(NP, I))
+                dma_fragment(ddst + dma_index(NP, I) * 1024, dsrc + dma_index(NP, I) * 1024, lane16);
 #endif
             fill(ii);
             __builtin_amdgcn_sched_barrier(0);
@@ -451,12 +490,12 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
         for (int a = 0; a < kAhead; ++a)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wq[a][p] = wq[a + 1][p];
+            for (int p = 0; p < NP; ++p) wq[a][p] = wq[a + 1][p];
         if constexpr (GQ == kGranuleGroups - 1) wa = wa_next;
     };
     auto no_fill = [](auto) {};
 
-    u32x4 bf[2][2][3];                                 // B fragments [k-step parity][column block][part] in use / in preparation
+    u32x4 bf[2][2][NP];                                // B fragments [k-step parity][column block][part] in use / in preparation
     UnitState us[8];                                   // activation units in flight
 #ifdef FF_SPLIT_SKIP_OPS
 #pragma unroll
@@ -466,20 +505,24 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) bf[i][j][k] = u32x4{0u, 0u, 0u, 0u};
+            for (int k = 0; k < NP; ++k) bf[i][j][k] = u32x4{0u, 0u, 0u, 0u};
 #endif
 
-    // The micro-op the plan `KIND` pins to gap G of a span: the units turn row tiles (2 sn, 2 sn + 1) of `T` into the
+    // The micro-ops the plan `KIND` pins to gap G of a span: the units turn row tiles (2 sn, 2 sn + 1) of `T` into the
     // fragments of k-step sn.  Unit u: column block u >> 2, word u & 3 = registers 2 (u & 1), 2 (u & 1) + 1 of row tile
     // 2 sn + ((u >> 1) & 1).
-    auto act_gap = [&](auto kind, auto gg, auto snn, f32x4 (&T)[NR][2], u32x4 (&dst)[2][3]) __attribute__((always_inline)) {
+    auto act_gap = [&](auto kind, auto gg, auto snn, f32x4 (&T)[NR][2], u32x4 (&dst)[2][NP]) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind)::value, G = decltype(gg)::value, sn = decltype(snn)::value;
-        constexpr int U = KIND == 0 ? GapPlans<TANGENTS>::k0.unit[G] : GapPlans<TANGENTS>::k1.unit[G];
-        if constexpr (U >= 0) {
-            constexpr int J = KIND == 0 ? GapPlans<TANGENTS>::k0.micro[G] : GapPlans<TANGENTS>::k1.micro[G];
-            constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
-            unit_micro<TANGENTS, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
-        }
+        sfor<kMaxPerGap>([&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            constexpr int N = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.n[G] : GapPlans<TANGENTS, NP>::k1.n[G];
+            if constexpr (K < N) {
+                constexpr int U = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.unit[G][K] : GapPlans<TANGENTS, NP>::k1.unit[G][K];
+                constexpr int J = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.micro[G][K] : GapPlans<TANGENTS, NP>::k1.micro[G][K];
+                constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
+                unit_micro<TANGENTS, NP, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
+            }
+        });
     };
 
     // A hidden -> hidden layer (reads P, writes Cc) or, with OUT, the output layer (reads P, writes O).
@@ -495,12 +538,12 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 // interleaved so that eight independent chains cover each other's latencies
                 group(std::integral_constant<int, s % 8>{}, O, bf[s & 1], no_fill);
                 if constexpr (s < NS - 1) {
-                    sfor<micro_count(TANGENTS)>([&](auto jj) {
+                    sfor<micro_count(TANGENTS, NP)>([&](auto jj) {
                         sfor<8>([&](auto uu) {
                             constexpr int U = decltype(uu)::value;
                             constexpr int cb = U >> 2, word = U & 3, prt = 2 * (s + 1) + (word >> 1), r0 = 2 * (word & 1);
-                            unit_micro<TANGENTS, decltype(jj)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
-                                                                     bf[(s + 1) & 1][cb], word, is_tangent);
+                            unit_micro<TANGENTS, NP, decltype(jj)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
+                                                                         bf[(s + 1) & 1][cb], word, is_tangent);
                         });
                     });
                 }
@@ -511,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                     if constexpr (s == 3) FF_STAMP();
 #endif
                     group(std::integral_constant<int, rt % 8>{}, Cc[rt], bf[s & 1], [&](auto ii) {
-                        constexpr int G = rt * 12 + decltype(ii)::value;
+                        constexpr int G = rt * GG + decltype(ii)::value;
 #ifdef FF_SPLIT_STAMP_GAPS      // diagnostic: a stamp behind every MFMA of groups 0 and 1 of k-step 3
                         if constexpr (s == 3 && rt < 2) FF_STAMP();
 #endif
@@ -552,8 +595,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) v += hdr->cin[s] * ks[(s * 2 + cb) * 256];
             ks[(kSlots * 2 + cb) * 256] = v;
-            split2(v[0], v[1], yf[cb], 0);
-            split2(v[2], v[3], yf[cb], 1);
+            split2<NP>(v[0], v[1], yf[cb], 0);
+            split2<NP>(v[2], v[3], yf[cb], 1);
         }
 
         FF_STAMP();
@@ -562,9 +605,9 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             constexpr int rt = decltype(tt)::value;
             group(std::integral_constant<int, rt % 8>{}, A[rt], yf, [&](auto ii) {
                 constexpr int I = decltype(ii)::value;
-                if constexpr (rt == 0 && I == 11) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
+                if constexpr (rt == 0 && I == GG - 1) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
                 // row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
-                act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, rt * 12 + I>{},
+                act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, rt * GG + I>{},
                         std::integral_constant<int, 0>{}, A, bf[0]);
             });
         });

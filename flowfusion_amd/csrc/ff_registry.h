@@ -26,10 +26,11 @@ struct KernelEntry {
 extern const KernelEntry g_kernels[];
 extern const int g_n_kernels;
 
-// split-precision family (FF_PREC_BF16X3, ff_mlp_ode_split.hpp): width <= 256, dim <= 16, cond <= 16
+// split-precision family (FF_PREC_BF16X3 / FF_PREC_BF16X2, ff_mlp_ode_split.hpp): width <= 256, dim <= 16, cond <= 16
 struct SplitKernelEntry {
     int n_hidden;   // hidden layers (compile-time in this family)
     int tangents;   // 1: Hutchinson-capable instantiation (value / tangent column pairs)
+    int parts;      // bf16 parts per fp32 operand: 3 (truncation, six products) or 2 (round to nearest, three products)
     LaunchFn launch;
     const char* name;
 };

@@ -6,8 +6,8 @@
 // kidx(s, q, j) of k-step s.  kidx is the order in which the registers of two fp32 accumulator tiles line up as the B
 // operand of the next layer: a 16x16 accumulator tile keeps rows 4 q + i (i < 4) on quad q, the B operand wants k slots
 // 8 q + j (j < 8) there, so slots j < 4 of k-step s are rows 4 q + j of row tile 2s and slots j >= 4 are rows
-// 4 q + (j - 4) of row tile 2s + 1.  A GROUP = the three fragments [hi, mid, lo] of one (row tile, k-step) = 12 MFMAs
-// (six products x two column blocks of 16 samples); a GRANULE = 8 groups = 24 KiB, the unit of the LDS pipeline.
+// 4 q + (j - 4) of row tile 2s + 1.  A GROUP = the fragments [hi, mid(, lo)] of one (row tile, k-step) = 12 MFMAs with three
+// parts (six products x two column blocks of 16 samples), 6 with two; a GRANULE = 8 groups, the unit of the LDS pipeline.
 // Stream of one evaluation, in consumption order (width 256: 16 row tiles, 8 k-steps):
 //     layer 1          one k-step (features 0..15 = state dimensions, 16..31 = conditional inputs): for row tile rt
 //     hidden layer l   for k-step s < 8:  for row tile rt < 16:  group (rt, s)                       l = 1 .. NH-1
@@ -26,10 +26,14 @@ constexpr int kRowTiles = 16;         // 16-row tiles of a 256-wide layer
 constexpr int kKSteps = 8;            // 32-feature k-steps of a 256-wide layer
 constexpr int kWidth = 256;
 constexpr int kFragBytes = 1024;
-constexpr int kGroupFrags = 3;
 constexpr int kGranuleGroups = 8;
-constexpr int kGranuleBytes = kFragBytes * kGroupFrags * kGranuleGroups;     // 24 KiB
 constexpr int kBuffers = 3;
+
+// PARTS = bf16 parts per fp32 operand: 3 (FF_PREC_BF16X3: hi / mid / lo by truncation, exact; six products per term) or
+// 2 (FF_PREC_BF16X2: hi / mid by round-to-nearest, 16 significand bits; three products per term).  A group carries
+// `parts` fragments, a granule 8 groups.
+FF_HD constexpr int products_of(int parts) { return parts == 3 ? 6 : 3; }
+FF_HD constexpr int granule_bytes(int parts) { return kFragBytes * parts * kGranuleGroups; }      // 24 KiB / 16 KiB
 
 // input feature held by element j (0..7) of quad q in the fragment of k-step s
 FF_HD constexpr int kidx(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
@@ -42,23 +46,23 @@ FF_HD constexpr int granules_per_eval(int n_hidden)
     return (kGroupsL1 + (n_hidden - 1) * kGroupsHid + kGroupsOut) / kGranuleGroups;
 }
 // 4-byte words of the fragment stream / of the whole packed buffer
-FF_HD constexpr size_t stream_words(int n_hidden) { return (size_t)granules_per_eval(n_hidden) * (kGranuleBytes / 4); }
-FF_HD constexpr size_t total_words(int n_hidden) { return stream_words(n_hidden) + (size_t)(n_hidden - 1) * kWidth + 16; }
+FF_HD constexpr size_t stream_words(int n_hidden, int parts) { return (size_t)granules_per_eval(n_hidden) * (granule_bytes(parts) / 4); }
+FF_HD constexpr size_t total_words(int n_hidden, int parts) { return stream_words(n_hidden, parts) + (size_t)(n_hidden - 1) * kWidth + 16; }
 
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
-    int wbuf;    // kBuffers x 24 KiB weight granules
+    int wbuf;    // kBuffers weight granules (24 KiB each with three parts, 16 KiB with two)
     int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (kSlots + 2) x 2 x 256 threads x 16 B
     int c1;      // 2 x H floats: first-layer bias of the current / next evaluation
     int hbias;   // (NH-1) x H floats + 16: hidden->hidden and output biases
     int zero;    // H floats of zeros (what tangent columns read instead of a bias)
     int total;
 };
-FF_HD constexpr LdsMap lds_map(int H, int n_hidden)
+FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts)
 {
     LdsMap m{};
     m.wbuf = 0;
-    m.slots = kBuffers * kGranuleBytes;
+    m.slots = kBuffers * granule_bytes(parts);
     m.c1 = m.slots + (7 + 2) * 2 * 256 * 16;
     m.hbias = m.c1 + 2 * H * 4;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;

@@ -80,9 +80,14 @@ extern "C" {
  *                   bits) and a product is the sum of the six bf16 MFMAs whose parts' exponents sum to more than
  *                   2^-24 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32: fp32-class
  *                   accuracy (error ~1e-7 relative to sum |w||x|, like an fp32 dot product) at the bf16 matrix
- *                   rate.  State-only and Hutchinson modes, SiLU networks; see DESIGN.md for coverage. */
+ *                   rate.  State-only and Hutchinson modes, SiLU networks; see DESIGN.md for coverage.
+ *   FF_PREC_BF16X2  opt-in: two bf16 parts by round-to-nearest (hi + mid = the operand to 16 significand bits) and
+ *                   the three products hi.hi, hi.mid, mid.hi: operands rounded to 2^-17 relative (TF32 keeps 2^-11),
+ *                   unbiased, fp32 accumulation; error of a 256-term layer ~4e-7 relative to sum |w||x| in the mean
+ *                   (fp32: 2e-8) at half the MFMAs of FF_PREC_BF16X3.  Same coverage as FF_PREC_BF16X3. */
 #define FF_PREC_F32        0
 #define FF_PREC_BF16X3     1
+#define FF_PREC_BF16X2     2
 
 /* evaluation-row flag bits (word 3 of the row header) */
 #define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */

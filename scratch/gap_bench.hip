@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256, 1) void gap_kernel(float* out, unsigned long l
                     else { b[3] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, a0), 0x07060302u); }
                 }
             }
+#ifdef ALIGN_WAVES     // the product kernel's barrier every 8 groups keeps the four wavefronts of a workgroup in step
+            if constexpr (G % 96 == 95) __builtin_amdgcn_s_barrier();
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     }

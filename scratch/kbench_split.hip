@@ -13,20 +13,23 @@ int main(int argc, char** argv)
 #ifndef KB_NH
 #define KB_NH 4
 #endif
-    const int NH = KB_NH, H = 256, D = 16;
+#ifndef KB_NP
+#define KB_NP 3
+#endif
+    const int NH = KB_NH, H = 256, D = 16, NP = KB_NP;
     long long B = argc > 1 ? atoll(argv[1]) : (1 << 20);
     int n_evals = argc > 2 ? atoi(argv[2]) : 100;
-    const size_t nw = total_words(NH);
+    const size_t nw = total_words(NH, NP);
     std::vector<uint32_t> hw(nw);
     srand(3);
     // fragments: two bf16 per word, magnitudes ~0.06 (hi), 2^-8 and 2^-16 of that for mid / lo: a granule is 8 x [hi, mid, lo] x 1 KiB
-    for (size_t i = 0; i < stream_words(NH); ++i) {
-        const int part = (int)((i / 256) % 3);
+    for (size_t i = 0; i < stream_words(NH, NP); ++i) {
+        const int part = (int)((i / 256) % NP);
         auto bf = [&](float scale) { float v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.12f * scale; uint32_t u; memcpy(&u, &v, 4); return u >> 16; };
         const float sc = part == 0 ? 1.f : (part == 1 ? 1.f / 256 : 1.f / 65536);
         hw[i] = bf(sc) | (bf(sc) << 16);
     }
-    for (size_t i = stream_words(NH); i < nw; ++i) { float v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.1f; memcpy(&hw[i], &v, 4); }
+    for (size_t i = stream_words(NH, NP); i < nw; ++i) { float v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.1f; memcpy(&hw[i], &v, 4); }
     const int stride = 32 + H;
     std::vector<float> ht((size_t)n_evals * stride, 0.f);
     for (int e = 0; e < n_evals; ++e) {
@@ -36,7 +39,7 @@ int main(int argc, char** argv)
         for (int i = 0; i < H; ++i) ht[(size_t)e * stride + 32 + i] = ((rand() / (float)RAND_MAX) - 0.5f) * 0.1f;
     }
     if (getenv("KB_ZERO")) {          // all activations exactly zero: state 0, biases 0 (weights stay random)
-        for (size_t i = stream_words(NH); i < nw; ++i) hw[i] = 0;
+        for (size_t i = stream_words(NH, NP); i < nw; ++i) hw[i] = 0;
         for (int e = 0; e < n_evals; ++e)
             for (int i = 0; i < H; ++i) ht[(size_t)e * stride + 32 + i] = 0.f;
     }
@@ -54,9 +57,9 @@ int main(int argc, char** argv)
     ff::KernelArgs a; memset(&a, 0, sizeof(a));
     a.x_in = dx; a.x_out = dy; a.wpack = dw; a.etab = dt; a.batch = B; a.n_evals = n_evals; a.n_hidden = NH; a.dim = D;
     a.etab_stride = stride; a.wpack_floats = (int)nw; a.debug_stamps = dbg;
-    auto kern = mlp_ode_split_kernel<NH, false>;
+    auto kern = mlp_ode_split_kernel<NH, false, NP>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned lds = (unsigned)lds_map(H, NH).total;
+    const unsigned lds = (unsigned)lds_map(H, NH, NP).total;
     const unsigned grid = (unsigned)((B + 127) / 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a); CK(hipDeviceSynchronize());
@@ -104,7 +107,7 @@ int main(int argc, char** argv)
             for (int k = 0; k < 8; ++k) printf(" %llu", s[3 + l * 8 + k] - s[2 + l * 8 + k]);
             printf(" |");
         }
-        if (e == 0) printf(" rhs+bookkeeping %llu | total %llu (MFMA-only ideal %d)\n", st[per] - s[per - 1], st[per] - s[0], 4896 * 16);
+        if (e == 0) printf(" rhs+bookkeeping %llu | total %llu (MFMA-only ideal %d)\n", st[per] - s[per - 1], st[per] - s[0], (NP == 3 ? 4896 : 2448) * 16);
         else printf("\n");
     }
 #endif

@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from flowfusion_amd.diffusion import MLP, VPSDE, ScoreModel  # noqa: E402
 
-prec = "f32" if "--f32" in sys.argv else "bf16x3"
+prec = "f32" if "--f32" in sys.argv else ("bf16x2" if "--x2" in sys.argv else "bf16x3")
 hutch = "--hutch" in sys.argv
 n = 3
 dev = torch.device("cuda", 0)

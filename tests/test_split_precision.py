@@ -1,4 +1,4 @@
-"""precision="bf16x3": the opt-in split-precision kernels (csrc/ff_mlp_ode_split.hpp, FF_PREC_BF16X3).
+"""precision="bf16x3" / "bf16x2": the opt-in split-precision kernels (csrc/ff_mlp_ode_split.hpp, FF_PREC_BF16X3 / _BF16X2).
 
 CPU tier: plan selection, the host packer (the fragment stream decodes back to the fp32 weights bit for bit:
 hi + mid + lo is an exact three-way split), error behaviour.
@@ -6,6 +6,8 @@ GPU tier: the same parity battery the f32 path passes -- golden hybrids, oracle 
 (BASELINE configs 2 and 3 included), ragged batches, Hutchinson tangents, conditional inputs, flows -- at the SAME
 tolerances (2e-5; north_star's bar for log_prob is 1e-4): six bf16 products per term carry ~24 significand bits, so
 the split path sits at fp32 rounding level, not at bf16 level (a single-product bf16 path would miss by 1e-2).
+"bf16x2" (two round-to-nearest parts, three products: operands to 16 bits, unbiased) runs the same battery at the same
+tolerances: its per-layer error is ~20x an fp32 dot product's and still two orders below the bar.
 """
 import ctypes
 
@@ -22,6 +24,7 @@ from tests._util import flow_model, flow_oracle, golden_names, load_golden, max_
 DEV = "cuda"
 STATE_TOL = 2e-5
 LOGP_TOL = 2e-5
+PRECS = ["bf16x3", "bf16x2"]
 
 
 def _kidx(s, q, j):
@@ -97,6 +100,35 @@ def test_plan_and_packer_roundtrip(built_library):
     assert np.array_equal(tail[512:512 + 11], bs[3]) and not tail[512 + 11:].any()
 
 
+def test_two_part_packer_rounds_to_nearest(built_library):
+    """FF_PREC_BF16X2: groups of two fragments; hi = bf16(w) and mid = bf16(w - hi), both round-to-nearest-even: the pair
+    carries the weight to 16 significand bits (|error| <= 2^-17 |w|), the biases stay fp32."""
+    torch.manual_seed(4)
+    sm = D.ScoreModel(D.MLP(7, 2, 8, [256, 128]), D.VPSDE(), no_sigma=True, precision="bf16x2").eval()
+    net = sm._net()
+    plan = net.plan(MODE_STATE)
+    assert (plan.precision, plan.tile, plan.width, plan.n_hidden) == (2, 32, 256, 2)
+    assert _native.kernel_name(plan) == "mlp_ode_split2_h256_n2_t0" and _native.kernel_name(net.plan(MODE_HUTCH)) == "mlp_ode_split2_h256_n2_t1"
+    words = net.wpack("cpu", MODE_STATE).numpy().view(np.uint32)
+    n_gran = (16 + 128 + 8) // 8
+    assert words.size == n_gran * 4096 + 256 + 16
+    W1 = sm.model.NN[1].weight.detach()                                  # [128, 256]
+    hi = W1.bfloat16().float()
+    mid = (W1 - hi).bfloat16().float()
+    for s_, rt, lane in ((0, 0, 0), (3, 5, 17), (7, 7, 63), (5, 2, 40)):
+        g = 16 + s_ * 16 + rt
+        frag = words[g * 512:(g + 1) * 512].reshape(2, 64, 4)
+        halves = np.stack([frag & 0xFFFF, frag >> 16], axis=-1).reshape(2, 64, 8)
+        vals = (halves.astype(np.uint32) << 16).view(np.float32)
+        row = 16 * rt + (lane & 15)
+        for j in range(8):
+            k = _kidx(s_, lane >> 4, j)
+            assert vals[0, lane, j] == hi[row, k].item() and vals[1, lane, j] == mid[row, k].item()
+            assert abs(float(vals[0, lane, j]) + float(vals[1, lane, j]) - W1[row, k].item()) <= 2.0 ** -17 * abs(W1[row, k].item())
+    tail = net.wpack("cpu", MODE_STATE).numpy()[n_gran * 4096:]
+    assert np.array_equal(tail[:128], sm.model.NN[1].bias.detach().numpy()) and np.array_equal(tail[256:256 + 7], sm.model.NN[2].bias.detach().numpy())
+
+
 def test_split_precision_scope_and_errors(built_library):
     mk = lambda **kw: _native.make_plan(kw.get("dim", 16), kw.get("cond", 0), kw.get("hidden", [256] * 4), kw.get("mode", MODE_STATE),
                                         kw.get("act", (_native.ACT_SILU, 0.0, 0.0)), _native.PREC_BF16X3)
@@ -130,23 +162,24 @@ def _logp_err(got, exp):
     return max_rel(got.cpu(), exp, floor=1.0)
 
 
-def _seeded(Dm, C, units, sde_name, no_sigma, seed):
+def _seeded(Dm, C, units, sde_name, no_sigma, seed, prec="bf16x3"):
     torch.manual_seed(seed)
     m = D.MLP(n_dimensions=Dm, n_conditionals=C, embedding_dimensions=8, units=units)
-    sm = D.ScoreModel(m, getattr(D, sde_name)(), no_sigma=no_sigma, precision="bf16x3").eval()
+    sm = D.ScoreModel(m, getattr(D, sde_name)(), no_sigma=no_sigma, precision=prec).eval()
     meta = dict(D=Dm, C=C, E=8, units=units, sde=sde_name, sde_kw={}, no_sigma=no_sigma)
     arrays = {k: v.detach().clone() for k, v in sm.state_dict().items()}
     return sm.to(DEV), score_oracle(meta, arrays), score_oracle(meta, arrays, torch.float64)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", [n for n in golden_names("hybrid_score_") if "cond32" not in n])
-def test_split_against_golden_hybrids(name, built_library):
+def test_split_against_golden_hybrids(name, prec, built_library):
     meta, a = load_golden(name)
     if meta["D"] > 16 or meta["C"] > 16:
         pytest.skip("outside the split family's shape envelope")
     sm = score_model(meta, a, DEV)
-    sm.precision = "bf16x3"
+    sm.precision = prec
     cond = a.get("cond")
     cond_d = None if cond is None else cond.to(DEV)
     for run in meta["runs"]:
@@ -175,10 +208,11 @@ CONFIGS = {
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", list(CONFIGS))
-def test_split_sampling_and_log_prob_against_oracle(name, built_library):
+def test_split_sampling_and_log_prob_against_oracle(name, prec, built_library):
     Dm, C, units, sde_name, no_sigma, method, nsteps, B = CONFIGS[name]
-    sm, so32, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 11)
+    sm, so32, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 11, prec)
     torch.manual_seed(1234)
     base = torch.randn(B, Dm)
     cond = torch.randn(B, C) if C else None
@@ -188,6 +222,7 @@ def test_split_sampling_and_log_prob_against_oracle(name, built_library):
     ref64 = so64.sample_ode_from_base(base.double(), None if cond is None else cond.double(), method, opts).float()
     e_gpu, e_cpu = _state_err(got, ref64), _state_err(so32.sample_ode_from_base(base, cond, method, opts), ref64)
     assert e_gpu < STATE_TOL, (name, e_gpu, e_cpu)
+    print(f"\n[{prec}] {name}: state error vs float64 {e_gpu:.2e} (fp32 CPU oracle {e_cpu:.2e})")
     # Hutchinson log-density (value / tangent column pairs): the reference's CPU-drawn probe
     sm.hutch = True
     Bl = min(B, 256)
@@ -206,9 +241,10 @@ def test_split_sampling_and_log_prob_against_oracle(name, built_library):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B", [1, 31, 32, 33, 127, 128, 129, 1000])
-def test_split_ragged_batches(B, built_library):
-    sm, so32, _ = _seeded(16, 0, [64, 64], "VPSDE", True, 15)
+def test_split_ragged_batches(B, prec, built_library):
+    sm, so32, _ = _seeded(16, 0, [64, 64], "VPSDE", True, 15, prec)
     torch.manual_seed(B)
     base = torch.randn(B, 16)
     opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 8}
@@ -220,7 +256,8 @@ def test_split_ragged_batches(B, built_library):
 
 
 @pytest.mark.gpu
-def test_split_flows_and_wrappers(built_library):
+@pytest.mark.parametrize("prec", PRECS)
+def test_split_flows_and_wrappers(prec, built_library):
     torch.manual_seed(21)
     f = F.ConditionalODEFlow(target_dimension=16, conditional_dimension=6, hidden_units=[256, 256, 256],
                              target_shift=torch.randn(16), target_scale=torch.rand(16) + 0.5,
@@ -228,7 +265,7 @@ def test_split_flows_and_wrappers(built_library):
     sd = {k: v.detach().clone() for k, v in f.state_dict().items()}
     fo64 = flow_oracle(sd, torch.float64)
     f = f.to(DEV)
-    f.precision = "bf16x3"
+    f.precision = prec
     xT, cond = torch.randn(200, 16), torch.randn(200, 6) * 2
     opts = {"step_size": 1.0 / 40}
     got = f.sample(xT.to(DEV), cond.to(DEV), method="rk4", options=opts)               # output affine in the epilogue
@@ -241,22 +278,23 @@ def test_split_flows_and_wrappers(built_library):
     lp32 = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts, hutchinson=True)
     assert _logp_err(lp, lp32.cpu()) < LOGP_TOL
     # what the family does not do raises instead of switching arithmetic silently
-    f.precision = "bf16x3"
+    f.precision = prec
     with pytest.raises(NotImplementedError, match="bf16x3"):
         f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)           # exact trace
     with pytest.raises(NotImplementedError, match="fixed grids"):
         f.sample(xT.to(DEV), cond.to(DEV))                                              # adaptive dopri5
-    sm, _, _ = _seeded(4, 0, [64, 64], "VPSDE", True, 5)
+    sm, _, _ = _seeded(4, 0, [64, 64], "VPSDE", True, 5, prec)
     with pytest.raises(NotImplementedError, match="noise"):
         sm.sample_sde((16, 4), steps=5)
 
 
 @pytest.mark.gpu
-def test_split_full_size_properties_and_speed(built_library):
+@pytest.mark.parametrize("prec", PRECS)
+def test_split_full_size_properties_and_speed(prec, built_library):
     """BASELINE config 2 at 2^20: determinism, batch-shape invariance (bitwise), oracle on a subsample, agreement
     with the f32 kernels -- and the reason the family exists: it must be clearly faster."""
     import time
-    sm, so32, so64 = _seeded(16, 0, [256] * 4, "VPSDE", True, 17)
+    sm, so32, so64 = _seeded(16, 0, [256] * 4, "VPSDE", True, 17, prec)
     B = 1 << 20
     opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 100}
     g = torch.Generator(device=DEV).manual_seed(1234)
@@ -282,6 +320,6 @@ def test_split_full_size_properties_and_speed(built_library):
     torch.cuda.synchronize()
     t_f32 = time.perf_counter() - t0
     assert ((x - y).abs().max() / y.abs().max()).item() < STATE_TOL
-    print(f"\n[split] 2^20 x 100-step RK4: bf16x3 {t_split * 1e3:.1f} ms ({B / t_split:.3g} samples/s), "
+    print(f"\n[split] 2^20 x 100-step RK4: {prec} {t_split * 1e3:.1f} ms ({B / t_split:.3g} samples/s), "
           f"f32 {t_f32 * 1e3:.1f} ms ({B / t_f32:.3g} samples/s), speed-up {t_f32 / t_split:.2f}x")
     assert t_split < 0.8 * t_f32
