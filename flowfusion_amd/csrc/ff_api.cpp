@@ -363,8 +363,9 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     if (a->mode != FF_MODE_STATE && a->mode != FF_MODE_HUTCH) return a->mode == FF_MODE_EXACT ? FF_ERR_UNSUPPORTED : FF_ERR_BADARG;
     if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
     if (a->mode == FF_MODE_HUTCH && (!a->probe || !a->dlogp_out)) return FF_ERR_BADARG;
-    // what this family does not carry: noise rows, adaptive-step inputs / outputs, the Jacobian output
-    if (a->noise || a->k1_in || a->kl1_in || a->n_aux != 0 || a->jac_out) return FF_ERR_UNSUPPORTED;
+    // what this family does not carry: noise rows, the Jacobian output
+    if (a->noise || a->jac_out) return FF_ERR_UNSUPPORTED;
+    if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
     if (a->batch == 0) return FF_OK;
     ff::KernelArgs ka;
     memset(&ka, 0, sizeof(ka));
@@ -372,6 +373,8 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.dlogp_out = a->dlogp_out; ka.wpack = a->wpack; ka.etab = a->etab;
     ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
     ka.status = a->status; ka.batch = a->batch; ka.dlogp_in = a->dlogp_in;
+    ka.k1_in = a->k1_in; ka.kl1_in = a->kl1_in; ka.n_aux = a->n_aux;
+    for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
     ka.n_tangent = k.tangents ? 1 : 0;
     ka.etab_stride = FF_ROW_HDR + plan->width;

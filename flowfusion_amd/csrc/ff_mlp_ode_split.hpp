@@ -38,7 +38,8 @@
 //
 // Scope of this family: width 256, dim <= 16, cond <= 16 (state and conditional inputs share the first layer's single
 // k-step), SiLU, 1-6 hidden layers, FF_MODE_STATE and FF_MODE_HUTCH, any fixed-grid table (<= 7 stage slots, kept in
-// LDS with the state); no noise rows, no adaptive-step outputs, no Jacobian output.
+// LDS with the state) and the adaptive-step inputs / outputs (k1_in, aux_out: one attempted step per launch); no noise
+// rows, no Jacobian output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -368,6 +369,23 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) kl[s][0] = kl[s][1] = 0.f;
     float lp[2] = {0.f, 0.f};
+    // adaptive stepping (one attempted step per launch): stage slot 0 is the derivative at the step start, supplied by
+    // the caller (FSAL of the step before); its divergence is carried by ONE lane of the sample's tangent column
+    if (args.k1_in) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = 4 * qd + i;
+                if (d < D && !is_tangent) v[i] = args.k1_in[sample[cb] * D + d];
+            }
+            ks[(0 * 2 + cb) * 256] = v;
+            if constexpr (TANGENTS) {
+                if (args.kl1_in && is_tangent && qd == 0) kl[0][cb] = args.kl1_in[sample[cb]];
+            }
+        }
+    }
 #ifdef FF_SPLIT_STAMPS          // diagnostic builds only (scratch/kbench_split.hip): cycle stamps of wavefront 0, evaluations 2 and 3
     int stamp_i = 0;
     bool stamp_on = false;
@@ -689,6 +707,45 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             }
             if (writer && qd == 0 && args.dlogp_out)
                 args.dlogp_out[sample[cb]] = (args.dlogp_in ? args.dlogp_in[sample[cb]] : 0.f) + tot;
+        }
+        // auxiliary outputs of an adaptive step: aux_j = use_y_j * y + sum_s coef_j[s] * k[s] (new state, last stage,
+        // dense-output midpoint, error estimate); coefficients in the two rows that follow the evaluation rows
+        if (args.n_aux > 0) {
+            HdrPtr t0h = (HdrPtr)(args.etab + (size_t)args.n_evals * args.etab_stride);
+            HdrPtr t1h = (HdrPtr)(args.etab + (size_t)(args.n_evals + 1) * args.etab_stride);
+            const uint32_t use_y = t0h->flags;
+            const f32x4 y0 = ks[((kSlots + 1) * 2 + cb) * 256];
+            sfor<kAux>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (j < args.n_aux) {
+                    HdrPtr th = (j < 2) ? t0h : t1h;
+                    float c[kSlots];
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) c[s] = (j & 1) ? th->cout[s] : th->cin[s];
+                    const float uy = ((use_y >> j) & 1u) ? 1.f : 0.f;
+                    f32x4 v = uy * y0;
+#pragma unroll
+                    for (int s = 0; s < kSlots; ++s) v += c[s] * ks[(s * 2 + cb) * 256];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int d = 4 * qd + i;
+                        if (writer && d < D && args.aux_out[j]) args.aux_out[j][sample[cb] * D + d] = v[i];
+                    }
+                    if constexpr (TANGENTS) {
+                        float part = 0.f;
+#pragma unroll
+                        for (int s = 0; s < kSlots; ++s) part = __builtin_fmaf(c[s], kl[s][cb], part);
+                        float tot = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int src = ((g << 4) | ((col + 1) & 15)) * 4;
+                            tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, part)));
+                        }
+                        if (writer && qd == 0 && args.aux_lp_out[j])
+                            args.aux_lp_out[j][sample[cb]] = uy * (args.dlogp_in ? args.dlogp_in[sample[cb]] : 0.f) + tot;
+                    }
+                }
+            });
         }
         const f32x4 xv = ks[((kSlots + 1) * 2 + cb) * 256];
         if (writer) {

@@ -222,10 +222,6 @@ class FusedNet:
         the time-dependent scalars and first-layer bias; ``sign`` = -1 for a decreasing span (solved
         in reversed time with the right-hand side negated).  ``launcher`` replaces the GPU launch in
         the CPU tests (kernel-semantics emulator)."""
-        if self.precision != "f32":
-            raise NotImplementedError(
-                f"precision={self.precision!r} integrates on fixed grids only; the adaptive dopri5 path (one launch per "
-                "attempted step) runs on the f32 kernels: pass method='rk4' / 'euler' / ... with options={'step_size': h}")
         plan = self.plan(mode)
         width = plan.width
         words = _native.plan_words(plan)

@@ -149,8 +149,6 @@ def test_split_precision_scope_and_errors(built_library):
     sm.precision = "bf16x3"
     n16 = sm._net()
     assert n16 is not n32 and n16.plan(MODE_STATE).precision == 1 and n32.plan(MODE_STATE).precision == 0
-    with pytest.raises(NotImplementedError, match="fixed grids"):
-        n16.make_step(None, 1.0, MODE_STATE, "cpu")
 
 
 # ---- GPU tier ------------------------------------------------------------------------------------------------------
@@ -242,6 +240,33 @@ def test_split_sampling_and_log_prob_against_oracle(name, prec, built_library):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", PRECS)
+def test_split_adaptive_default_calls(prec, built_library):
+    """The reference's default arguments (adaptive dopri5; diffusion.py:566-640, 756-815) on the split kernels: one launch per
+    attempted step with the FSAL stage preloaded and the new state / last stage / midpoint / error estimate leaving as
+    combinations of the stage slots.  Against the oracle's dopri5 (two adaptive solves: 2e-4), and the step sequence of
+    the f32 kernels (same controller, fp32-class right-hand sides: same number of attempts)."""
+    sm, so32, so64 = _seeded(16, 3, [256, 256, 200], "VESDE", False, 23, prec)
+    torch.manual_seed(5)
+    base, cond = torch.randn(300, 16), torch.randn(300, 3)
+    x0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV))
+    stats = dict(sm.last_solver_stats)
+    ref = so64.sample_ode_from_base(base.double(), cond.double(), "dopri5", None, atol=1e-4, rtol=1e-4).float()
+    assert _state_err(x0, ref) < 2e-4
+    sm.hutch = True
+    xd = torch.randn(64, 16) * 3
+    torch.manual_seed(9)
+    lp = sm.log_prob(xd.to(DEV), conditional=cond[:64].to(DEV))
+    e = sm.e.cpu()
+    ref = so64.log_prob(xd.double(), cond[:64].double(), "dopri5", {"min_step": 1e-6}, "hutch", e.double(), atol=1e-4, rtol=1e-4).float()
+    assert _logp_err(lp, ref) < 2e-4
+    sm.hutch = False
+    sm.precision = "f32"
+    y0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV))
+    assert sm.last_solver_stats == stats and _state_err(x0, y0.cpu()) < STATE_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B", [1, 31, 32, 33, 127, 128, 129, 1000])
 def test_split_ragged_batches(B, prec, built_library):
     sm, so32, _ = _seeded(16, 0, [64, 64], "VPSDE", True, 15, prec)
@@ -281,8 +306,11 @@ def test_split_flows_and_wrappers(prec, built_library):
     f.precision = prec
     with pytest.raises(NotImplementedError, match="bf16x3"):
         f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)           # exact trace
-    with pytest.raises(NotImplementedError, match="fixed grids"):
-        f.sample(xT.to(DEV), cond.to(DEV))                                              # adaptive dopri5
+    # the reference's default call -- adaptive dopri5, one launch per attempted step -- on the split kernels
+    ga = f.sample(xT.to(DEV), cond.to(DEV))
+    assert _state_err(ga, fo64.sample(xT.double(), cond.double(), "dopri5", None, atol=1e-9, rtol=1e-7).float()) < 2e-4
+    lpa = f.log_prob(x.to(DEV), cond[:48].to(DEV), hutchinson=True)                     # adaptive, Hutchinson probe
+    assert lpa.shape == (48,) and torch.isfinite(lpa).all()
     sm, _, _ = _seeded(4, 0, [64, 64], "VPSDE", True, 5, prec)
     with pytest.raises(NotImplementedError, match="noise"):
         sm.sample_sde((16, 4), steps=5)
