@@ -354,7 +354,7 @@ extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
     return (wide ? 1 : 4) * (plan->tile / (1 + nt));
 }
 
-// FF_PREC_BF16X3 launch: state-only / Hutchinson integration of a table without noise rows
+// FF_PREC_BF16X3 / BF16X2 launch: state-only (Euler-Maruyama noise rows included) / Hutchinson integration of a table
 static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
 {
     if (!a->x_in || !a->x_out || !a->wpack || !a->etab || a->batch < 0 || a->n_evals < 0) return FF_ERR_BADARG;
@@ -363,8 +363,9 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     if (a->mode != FF_MODE_STATE && a->mode != FF_MODE_HUTCH) return a->mode == FF_MODE_EXACT ? FF_ERR_UNSUPPORTED : FF_ERR_BADARG;
     if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
     if (a->mode == FF_MODE_HUTCH && (!a->probe || !a->dlogp_out)) return FF_ERR_BADARG;
-    // what this family does not carry: noise rows, the Jacobian output
-    if (a->noise || a->jac_out) return FF_ERR_UNSUPPORTED;
+    // what this family does not carry: the Jacobian output; noise rows with tangent columns
+    if (a->jac_out || (a->noise && k.tangents)) return FF_ERR_UNSUPPORTED;
+    if (a->noise && a->noise_stride < a->batch * (int64_t)plan->dim) return FF_ERR_BADARG;
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
     if (a->batch == 0) return FF_OK;
     ff::KernelArgs ka;
@@ -374,6 +375,8 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
     ka.status = a->status; ka.batch = a->batch; ka.dlogp_in = a->dlogp_in;
     ka.k1_in = a->k1_in; ka.kl1_in = a->kl1_in; ka.n_aux = a->n_aux;
+    ka.noise = a->noise; ka.noise_stride = a->noise_stride;
+    ka.rng_seed = a->rng_seed; ka.rng_sample_offset = a->rng_sample_offset; ka.rng_noise_base = a->rng_noise_base;
     for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
     ka.n_tangent = k.tangents ? 1 : 0;

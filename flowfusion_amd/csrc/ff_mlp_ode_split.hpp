@@ -38,8 +38,8 @@
 //
 // Scope of this family: width 256, dim <= 16, cond <= 16 (state and conditional inputs share the first layer's single
 // k-step), SiLU, 1-6 hidden layers, FF_MODE_STATE and FF_MODE_HUTCH, any fixed-grid table (<= 7 stage slots, kept in
-// LDS with the state) and the adaptive-step inputs / outputs (k1_in, aux_out: one attempted step per launch); no noise
-// rows, no Jacobian output.
+// LDS with the state), the adaptive-step inputs / outputs (k1_in, aux_out: one attempted step per launch) and, in the
+// state-only kernels, Euler-Maruyama noise rows (buffer or in-kernel Philox); no Jacobian output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,6 +47,7 @@
 #include "ff_layout.h"
 #include "ff_kernel_args.h"
 #include "ff_split_layout.h"
+#include "ff_philox.h"
 
 namespace ff {
 namespace split {
@@ -606,6 +607,21 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         const uint32_t flags = hdr->flags;
         const int slot = hdr->slot;
 
+        // Euler-Maruyama rows (state-only kernels): the row's slab of standard normals, requested now and used after the
+        // network (include/flowfusion_amd.h: noise[noise_idx * noise_stride + sample * dim + d], or drawn in the kernel)
+        f32x4 nz[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if constexpr (!TANGENTS) {
+            if ((flags & 2u) && args.noise) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const float* np = args.noise + (size_t)hdr->noise_idx * args.noise_stride + sample[cb] * D;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * qd + i < D) nz[cb][i] = np[4 * qd + i];
+                }
+            }
+        }
+
         // stage input  y = x + sum_s cin[s] k[s]  (parked in LDS slot kSlots for the right-hand side); its fragments
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -686,6 +702,27 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 if constexpr (TANGENTS) {
 #pragma unroll
                     for (int s = 0; s < kSlots; ++s) lp[cb] = __builtin_fmaf(hdr->cout[s], kl[s][cb], lp[cb]);
+                }
+            }
+        }
+        if constexpr (!TANGENTS) {
+            if (flags & 2u) {                          // x += g sqrt(|dt|) z
+                const float gn = hdr->gn;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    if (!args.noise) {                 // in-kernel noise: a lane's four registers are dimensions 4 qd .. 4 qd + 3
+                        const unsigned long long gs = (unsigned long long)(sample[cb] + args.rng_sample_offset);
+                        uint32_t c[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(hdr->noise_idx + args.rng_noise_base), (uint32_t)qd};
+                        philox4x32_10(c, (uint32_t)args.rng_seed, (uint32_t)(args.rng_seed >> 32));
+                        float z0, z1, z2, z3;
+                        box_muller(c[0], c[1], z0, z1);
+                        box_muller(c[2], c[3], z2, z3);
+                        nz[cb] = f32x4{z0, z1, z2, z3};
+                    }
+                    f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gn, nz[cb][i], v[i]);
+                    ks[((kSlots + 1) * 2 + cb) * 256] = v;
                 }
             }
         }

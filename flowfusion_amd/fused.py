@@ -174,8 +174,6 @@ class FusedNet:
         if x.dim() != 2 or x.shape[1] != self.dim:
             raise ValueError(f"expected a [batch, {self.dim}] state, got {tuple(x.shape)}")
         dev = x.device
-        if self.precision != "f32" and (noise is not None or rng is not None or bool((etab[:, 3].view(torch.int32) & 2).any())):
-            raise NotImplementedError(f"precision={self.precision!r} integrates ODEs only (no Euler-Maruyama noise rows)")
         plan = self.plan(mode)
         f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
         if self.cond_dim > 0:

@@ -267,6 +267,39 @@ def test_split_adaptive_default_calls(prec, built_library):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", PRECS)
+def test_split_euler_maruyama(prec, built_library):
+    """sample_sde under precision=: noise rows on the split kernels.  (1) the reference's loop with an injected normal
+    stream against the oracle (diffusion.py:510-563 restated), conditional VE model, 60 steps; (2) in-kernel counter-based
+    noise: equals the same kernel fed tests/_philox.py's numbers through the noise buffer, and is bitwise independent
+    of how the batch is cut into launches; (3) the public method runs and returns finite means."""
+    from tests._philox import normals
+    sm, so32, _ = _seeded(12, 4, [128, 256], "VESDE", False, 31, prec)
+    B, steps = 200, 60
+    torch.manual_seed(2)
+    prior = torch.randn(B, 12) * float(sm.sde.sigma_max)
+    cond = torch.randn(B, 4)
+    draws = [torch.randn(B, 12) for _ in range(steps)]
+    it = iter(draws)
+    got = sm._sample_sde_from(prior.to(DEV), lambda like: next(it).to(DEV), cond.to(DEV), steps)
+    ref = so32.sample_sde(prior, draws, cond, steps=steps)
+    assert _state_err(got, ref) < STATE_TOL
+    seed, off = 24680, 7000
+    a = sm._sample_sde_from(prior.to(DEV), None, cond.to(DEV), 12, rng=(seed, off))
+    z = torch.from_numpy(normals(seed, off, B, 12, list(range(12))))
+    it = iter(z)
+    b = sm._sample_sde_from(prior.to(DEV), lambda like: next(it).to(DEV), cond.to(DEV), 12)
+    assert _state_err(a, b.cpu()) < STATE_TOL
+    parts = [sm._sample_sde_from(prior[lo:hi].to(DEV), None, cond[lo:hi].to(DEV), 12, rng=(seed, off + lo))
+             for lo, hi in ((0, 37), (37, 165), (165, B))]
+    assert torch.equal(torch.cat(parts), a)
+    torch.manual_seed(4)
+    out = sm.sample_sde((64, 12), conditional=cond[:64].to(DEV), steps=20)
+    assert out.shape == (64, 12) and torch.isfinite(out).all()
+    assert _native.kernel_name(sm._net().plan(0)).startswith("mlp_ode_split")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B", [1, 31, 32, 33, 127, 128, 129, 1000])
 def test_split_ragged_batches(B, prec, built_library):
     sm, so32, _ = _seeded(16, 0, [64, 64], "VPSDE", True, 15, prec)
@@ -311,9 +344,6 @@ def test_split_flows_and_wrappers(prec, built_library):
     assert _state_err(ga, fo64.sample(xT.double(), cond.double(), "dopri5", None, atol=1e-9, rtol=1e-7).float()) < 2e-4
     lpa = f.log_prob(x.to(DEV), cond[:48].to(DEV), hutchinson=True)                     # adaptive, Hutchinson probe
     assert lpa.shape == (48,) and torch.isfinite(lpa).all()
-    sm, _, _ = _seeded(4, 0, [64, 64], "VPSDE", True, 5, prec)
-    with pytest.raises(NotImplementedError, match="noise"):
-        sm.sample_sde((16, 4), steps=5)
 
 
 @pytest.mark.gpu
