@@ -245,6 +245,21 @@ def extra_configs(device):
                            {"launches": 1 if note == "philox" else -(-1000 // max(1, (1 << 28) // (B5 * 32))),
                             "note": "wall and kernel_ms bracket the whole public call (prior draw on the host like the "
                                     "reference, noise kernels, launches)"}))
+    # the same workload on the opt-in 16-bit-operand kernels (precision="bf16x2": dim <= 32, Euler-Maruyama rows on the split
+    # kernels); extra records, f32 stays the arithmetic of the entries above
+    f32_wall = {r["workload"].split("batch 2^20, ")[1][:5]: r["wall_ms"] for r in out[-2:]}
+    sm5.precision = "bf16x2"
+    for kind, kw, tag in (("torch noise", {}, "torch"), ("in-kernel counter-based noise, one launch", {"noise": "philox", "seed": 1}, "in-ke")):
+        sm5.sample_sde((256, 32), conditional=cond[:256].contiguous(), steps=8, **kw)
+        _, wall, kms = _timed(lambda: sm5.sample_sde((B5, 32), conditional=cond, steps=1000, **kw), device)
+        out.append({"workload": f"BASELINE configs[4] on precision='bf16x2' (opt-in): conditional 32-dim VE-SDE 4x256, 1000-step "
+                                f"Euler-Maruyama, batch 2^20, {kind}", "value": B5 / wall, "unit": "samples/s", "wall_ms": 1e3 * wall,
+                    "kernel": _native.kernel_name(sm5._net().plan(0)), "kernel_ms": kms, "dtype": "bf16x2-split, f32 accumulate",
+                    "speedup_vs_f32_entry": f32_wall[tag] / (1e3 * wall),
+                    "roofline": {"bound": "mfma", "achieved": 3 * 2.0 * mac5 * 1000 * B5 / (kms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": 3 * 2.0 * mac5 * 1000 * B5 / (kms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                                 "note": "executed bf16 MFMA work (three products per term, padding of the 40-feature first layer not "
+                                         "counted) vs the dense bf16 peak"}})
     return out
 
 

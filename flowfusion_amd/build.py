@@ -82,11 +82,13 @@ def _wide_name(tile, h, d, c, t) -> str:
 
 
 # split-precision family (width 256): (hidden layers, TANGENTS, bf16 parts per operand: 3 = FF_PREC_BF16X3, 2 = FF_PREC_BF16X2)
-SPLIT_INSTANCES = [(nh, t, parts) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1)]
+# ... and 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32, two-part kernels only)
+SPLIT_INSTANCES = [(nh, t, parts, 1) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1)] + \
+                  [(nh, t, 2, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1)]
 
 
-def _split_name(nh, t, parts=3) -> str:
-    return f"mlp_ode_split{'' if parts == 3 else parts}_h256_n{nh}_t{t}"
+def _split_name(nh, t, parts=3, dt=1) -> str:
+    return f"mlp_ode_split{'' if parts == 3 else parts}_h256{'' if dt == 1 else '_d' + str(dt)}_n{nh}_t{t}"
 
 
 def _has_coop(h, act=0) -> bool:
@@ -195,8 +197,8 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
         if not p.exists() or p.read_text() != src:
             p.write_text(src)
         files.append(p)
-    for nh, t, parts in SPLIT_INSTANCES:
-        name = _split_name(nh, t, parts)
+    for nh, t, parts, dt in SPLIT_INSTANCES:
+        name = _split_name(nh, t, parts, dt)
         src = f"""// generated by flowfusion_amd/build.py -- do not edit
 #include <atomic>
 #include "ff_registry.h"
@@ -204,7 +206,7 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
 namespace ff {{
 int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
 {{
-    auto kern = split::mlp_ode_split_kernel<{nh}, {'true' if t else 'false'}, {parts}>;
+    auto kern = split::mlp_ode_split_kernel<{nh}, {'true' if t else 'false'}, {parts}, {dt}>;
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
@@ -260,7 +262,7 @@ int launch_{name}_coop(const KernelArgs* a, unsigned grid, unsigned lds, hipStre
         [f"int launch_{_split_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in SPLIT_INSTANCES]
     )
     split_rows = ",\n".join(
-        f'    {{{i[0]}, {i[1]}, {i[2]}, launch_{_split_name(*i)}, "{_split_name(*i)}"}}' for i in SPLIT_INSTANCES
+        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, launch_{_split_name(*i)}, "{_split_name(*i)}"}}' for i in SPLIT_INSTANCES
     )
     rows = ",\n".join(
         f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, {i[7]}, launch_{_inst_name(*i)}, "{_inst_name(*i)}", '

@@ -286,10 +286,12 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
 // straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
 // accumulator registers at every control-flow join).
-template <int NH, bool TANGENTS, int NP = 3>
+template <int NH, bool TANGENTS, int NP = 3, int DT = 1>
 __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
     static_assert(NP == 2 || NP == 3, "two (round-to-nearest) or three (truncation) bf16 parts per operand");
+    static_assert(DT == 1 || (DT == 2 && NP == 2), "states of up to 32 dimensions: two-part kernels only (LDS)");
+    constexpr int NSLOT = slots_on_chip(DT);           // stage slots kept in LDS: 7 / 4
     constexpr int NR = kRowTiles;                      // 16 row tiles of 16 rows: width 256
     constexpr int NS = kKSteps;                        // 8 k-steps of 32 features
     constexpr int H = 16 * NR;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     const int col = lane & 15;                         // column within a column block
     const int lane16 = lane * 16;
     const int D = args.dim, C = args.cond_dim;
-    const LdsMap M = lds_map(H, NH, NP);
+    const LdsMap M = lds_map(H, NH, NP, DT);
 
     // ---- column roles: this lane serves one column of each of the two column blocks ---------------------------------
     const long long wave = (long long)blockIdx.x * 4 + wv;
@@ -324,64 +326,87 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         if (!live[cb]) sample[cb] = args.batch - 1;
     }
 
-    // ---- state / probe / conditional: register i of column block cb holds dimension 4 qd + i -------------------------
-    f32x4* const ks = (f32x4*)(lds + M.slots) + threadIdx.x;          // slot s, column block cb: ks[(s * 2 + cb) * 256]
+    // ---- state / probe / conditional: register i of tile t of column block cb holds dimension 16 t + 4 qd + i ----------
+    // slot s, column block cb, tile t: ks[SL(s, cb, t)]; slot NSLOT parks the stage input y, slot NSLOT + 1 is the state x
+    f32x4* const ks = (f32x4*)(lds + M.slots) + threadIdx.x;
+    auto SL = [](int s, int cb, int t) __attribute__((always_inline)) { return ((s * 2 + cb) * DT + t) * 256; };
     float ee[2] = {0.f, 0.f};                          // tangent lanes: e.e restricted to this lane's dimensions
-    u32x4 yf[2][NP];                                   // B fragments of the first layer: words 0,1 = state, 2,3 = conditional
+    // B fragments of the first layer.  DT = 1: one k-step, words 0,1 = state, 2,3 = conditional inputs.  DT = 2: k-step 0 =
+    // the state (words 0,1 = tile 0, words 2,3 = tile 1), k-step 1 = the conditional inputs (words 0,1; 2,3 zero)
+    u32x4 yf[DT][2][NP];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, cv = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 cv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = 16 * t + 4 * qd + i;
+                if (d < D) {
+                    if (!is_tangent) {
+                        float v = args.x_in[sample[cb] * D + d];
+                        if (args.in_shift) v = v - args.in_shift[d];
+                        if (args.in_scale) v = v / args.in_scale[d];
+                        xv[i] = v;
+                    } else {
+                        xv[i] = args.probe[sample[cb] * D + d];
+                    }
+                }
+            }
+            if constexpr (TANGENTS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ee[cb] = __builtin_fmaf(xv[i], xv[i], ee[cb]);
+            }
+            // the state x lives in LDS: it is touched twice per evaluation, and the live registers would spill inside the loop
+            ks[SL(NSLOT + 1, cb, t)] = xv;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int d = 4 * qd + i;
-            if (d < D) {
-                if (!is_tangent) {
-                    float v = args.x_in[sample[cb] * D + d];
-                    if (args.in_shift) v = v - args.in_shift[d];
-                    if (args.in_scale) v = v / args.in_scale[d];
-                    xv[i] = v;
-                } else {
-                    xv[i] = args.probe[sample[cb] * D + d];
-                }
-            }
             if (d < C && !is_tangent) cv[i] = args.cond[sample[cb] * C + d];
         }
-        if constexpr (TANGENTS) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ee[cb] = __builtin_fmaf(xv[i], xv[i], ee[cb]);
+        if constexpr (DT == 1) {
+            split2<NP>(cv[0], cv[1], yf[0][cb], 2);
+            split2<NP>(cv[2], cv[3], yf[0][cb], 3);
+        } else {
+            split2<NP>(cv[0], cv[1], yf[1][cb], 0);
+            split2<NP>(cv[2], cv[3], yf[1][cb], 1);
+            split2<NP>(0.f, 0.f, yf[1][cb], 2);
+            split2<NP>(0.f, 0.f, yf[1][cb], 3);
         }
-        // the state x lives in LDS (slot kSlots + 1; slot kSlots parks the stage input y): it is touched twice per
-        // evaluation, and 8 more live registers would spill inside the loop
-        ks[((kSlots + 1) * 2 + cb) * 256] = xv;
-        split2<NP>(cv[0], cv[1], yf[cb], 2);
-        split2<NP>(cv[2], cv[3], yf[cb], 3);
     }
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s)
+    for (int s = 0; s < NSLOT; ++s)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) ks[(s * 2 + cb) * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) ks[SL(s, cb, t)] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
-        const float* bsrc = args.wpack + (size_t)stream_words(NH, NP);
-        const int nb = (NH - 1) * H + 16;
+        const float* bsrc = args.wpack + (size_t)stream_words(NH, NP, DT);
+        const int nb = (NH - 1) * H + 16 * DT;
         for (int i = threadIdx.x; i < nb; i += 256) ((float*)(lds + M.hbias))[i] = bsrc[i];
     }
-    float kl[kSlots][2];
+    float kl[NSLOT][2];
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) kl[s][0] = kl[s][1] = 0.f;
+    for (int s = 0; s < NSLOT; ++s) kl[s][0] = kl[s][1] = 0.f;
     float lp[2] = {0.f, 0.f};
     // adaptive stepping (one attempted step per launch): stage slot 0 is the derivative at the step start, supplied by
     // the caller (FSAL of the step before); its divergence is carried by ONE lane of the sample's tangent column
     if (args.k1_in) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int d = 4 * qd + i;
-                if (d < D && !is_tangent) v[i] = args.k1_in[sample[cb] * D + d];
+            for (int t = 0; t < DT; ++t) {
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = 16 * t + 4 * qd + i;
+                    if (d < D && !is_tangent) v[i] = args.k1_in[sample[cb] * D + d];
+                }
+                ks[SL(0, cb, t)] = v;
             }
-            ks[(0 * 2 + cb) * 256] = v;
             if constexpr (TANGENTS) {
                 if (args.kl1_in && is_tangent && qd == 0) kl[0][cb] = args.kl1_in[sample[cb]];
             }
@@ -404,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 
     // ---- weight pipeline state (all wave-uniform) -----------------------------------------------------------------
     const unsigned char* const wbase = (const unsigned char*)args.wpack;
-    const long long wbytes = (long long)granules_per_eval(NH) * GB;
+    const long long wbytes = (long long)granules_per_eval(NH, DT) * GB;
     long long dpos = 0;                                // byte position in the stream of the NEXT granule to fetch
     unsigned rbuf = 0;                                 // LDS byte offset of the buffer the current granule is read from
     const int my_frag = wv * NDMA * 1024;              // this wavefront's quarter of a granule
@@ -546,16 +571,19 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 
     // A hidden -> hidden layer (reads P, writes Cc) or, with OUT, the output layer (reads P, writes O).
     // `refill` = LDS byte address of the bias vector the tiles of P are refilled with once consumed (their next use).
-    auto layer = [&](auto is_out, f32x4 (&P)[NR][2], f32x4 (&Cc)[NR][2], f32x4 (&O)[2], int refill) __attribute__((always_inline)) {
+    auto layer = [&](auto is_out, f32x4 (&P)[NR][2], f32x4 (&Cc)[NR][2], f32x4 (&O)[DT][2], int refill) __attribute__((always_inline)) {
         constexpr bool OUT = decltype(is_out)::value;
         P[0][0] = P[0][1] = bias_tile(refill, 0);      // row tiles 0, 1 were consumed at the end of the layer before
         P[1][0] = P[1][1] = bias_tile(refill, 1);
         sfor<NS>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
             if constexpr (OUT) {
-                // one group per k-step: the output layer is VALU-bound, its activation units run whole behind the group,
+                // DT groups per k-step: the output layer is VALU-bound, its activation units run whole behind them,
                 // interleaved so that eight independent chains cover each other's latencies
-                group(std::integral_constant<int, s % 8>{}, O, bf[s & 1], no_fill);
+                sfor<DT>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+                    group(std::integral_constant<int, (s * DT + t) % 8>{}, O[t], bf[s & 1], no_fill);
+                });
                 if constexpr (s < NS - 1) {
                     sfor<micro_count(TANGENTS, NP)>([&](auto jj) {
                         sfor<8>([&](auto uu) {
@@ -609,40 +637,52 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 
         // Euler-Maruyama rows (state-only kernels): the row's slab of standard normals, requested now and used after the
         // network (include/flowfusion_amd.h: noise[noise_idx * noise_stride + sample * dim + d], or drawn in the kernel)
-        f32x4 nz[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 nz[2][DT];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) nz[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (!TANGENTS) {
             if ((flags & 2u) && args.noise) {
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     const float* np = args.noise + (size_t)hdr->noise_idx * args.noise_stride + sample[cb] * D;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (4 * qd + i < D) nz[cb][i] = np[4 * qd + i];
+                    for (int t = 0; t < DT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (16 * t + 4 * qd + i < D) nz[cb][t][i] = np[16 * t + 4 * qd + i];
                 }
             }
         }
 
-        // stage input  y = x + sum_s cin[s] k[s]  (parked in LDS slot kSlots for the right-hand side); its fragments
+        // stage input  y = x + sum_s cin[s] k[s]  (parked in LDS slot NSLOT for the right-hand side); its fragments
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) v += hdr->cin[s] * ks[(s * 2 + cb) * 256];
-            ks[(kSlots * 2 + cb) * 256] = v;
-            split2<NP>(v[0], v[1], yf[cb], 0);
-            split2<NP>(v[2], v[3], yf[cb], 1);
-        }
+            for (int t = 0; t < DT; ++t) {
+                f32x4 v = ks[SL(NSLOT + 1, cb, t)];
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) v += hdr->cin[s] * ks[SL(s, cb, t)];
+                ks[SL(NSLOT, cb, t)] = v;
+                split2<NP>(v[0], v[1], yf[0][cb], 2 * t);
+                split2<NP>(v[2], v[3], yf[0][cb], 2 * t + 1);
+            }
 
         FF_STAMP();
         // ---- layer 1: [state | conditional] (one k-step) -> H, accumulators A already hold c1_e --------------------
-        sfor<NR>([&](auto tt) {
-            constexpr int rt = decltype(tt)::value;
-            group(std::integral_constant<int, rt % 8>{}, A[rt], yf, [&](auto ii) {
-                constexpr int I = decltype(ii)::value;
-                if constexpr (rt == 0 && I == GG - 1) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
-                // row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
-                act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, rt * GG + I>{},
-                        std::integral_constant<int, 0>{}, A, bf[0]);
+        sfor<DT>([&](auto kk) {
+            constexpr int k1 = decltype(kk)::value;                      // k-step of the first layer
+            sfor<NR>([&](auto tt) {
+                constexpr int rt = decltype(tt)::value;
+                group(std::integral_constant<int, rt % 8>{}, A[rt], yf[k1], [&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    if constexpr (k1 == 0 && rt == 0 && I == GG - 1) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
+                    // last k-step: row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14
+                    if constexpr (k1 == DT - 1)
+                        act_gap(std::integral_constant<int, 1>{}, std::integral_constant<int, rt * GG + I>{},
+                                std::integral_constant<int, 0>{}, A, bf[0]);
+                });
             });
         });
 
@@ -656,7 +696,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if (j + 1 <= NH - 1) return M.hbias + j * H * 4;
             return reads_A ? c1_next : M.hbias;
         };
-        f32x4 O[2];
+        f32x4 O[DT][2];
         sfor<NH>([&](auto jj) {
             constexpr int j = decltype(jj)::value + 1;                  // layers 1 .. NH-1 hidden -> hidden, NH = output
             constexpr bool reads_A = (j & 1) != 0;
@@ -664,7 +704,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 if constexpr (reads_A) layer(std::false_type{}, A, B, O, refill_for(j, true));
                 else layer(std::false_type{}, B, A, O, refill_for(j, false));
             } else {
-                O[0] = O[1] = bias_tile(M.hbias + (NH - 1) * H * 4, 0);       // output bias (16 rows)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) O[t][0] = O[t][1] = bias_tile(M.hbias + (NH - 1) * H * 4, t);   // output bias (16 DT rows)
                 if constexpr (reads_A) layer(std::true_type{}, A, B, O, refill_for(j, true));
                 else layer(std::true_type{}, B, A, O, refill_for(j, false));
             }
@@ -674,34 +715,42 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         // ---- right-hand side and stage bookkeeping ------------------------------------------------------------------
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const f32x4 yv = ks[(kSlots * 2 + cb) * 256];
-            f32x4 rhs;
+            float dot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = __builtin_fmaf(a_e, yv[i], b_e * O[cb][i]);
-                rhs[i] = is_tangent ? 0.f : v;
+            for (int t = 0; t < DT; ++t) {
+                const f32x4 yv = ks[SL(NSLOT, cb, t)];
+                f32x4 rhs;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = __builtin_fmaf(a_e, yv[i], b_e * O[t][cb][i]);
+                    rhs[i] = is_tangent ? 0.f : v;
+                }
+                ks[SL(slot, cb, t)] = rhs;
+                if constexpr (TANGENTS) {
+                    const f32x4 xv = ks[SL(NSLOT + 1, cb, t)];            // tangent lanes: the probe e
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dot = __builtin_fmaf(xv[i], O[t][cb][i], dot);
+                }
             }
-            ks[(slot * 2 + cb) * 256] = rhs;
             if constexpr (TANGENTS) {
-                const f32x4 xv = ks[((kSlots + 1) * 2 + cb) * 256];      // tangent lanes: the probe e
-                float dot = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dot = __builtin_fmaf(xv[i], O[cb][i], dot);
                 const float div = is_tangent ? __builtin_fmaf(a_e, ee[cb], b_e * dot) : 0.f;
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) kl[s][cb] = (slot == s) ? div : kl[s][cb];
+                for (int s = 0; s < NSLOT; ++s) kl[s][cb] = (slot == s) ? div : kl[s][cb];
             }
         }
         if (flags & 1u) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
 #pragma unroll
-                for (int s = 0; s < kSlots; ++s) v += hdr->cout[s] * ks[(s * 2 + cb) * 256];
-                ks[((kSlots + 1) * 2 + cb) * 256] = v;
+                for (int t = 0; t < DT; ++t) {
+                    f32x4 v = ks[SL(NSLOT + 1, cb, t)];
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) v += hdr->cout[s] * ks[SL(s, cb, t)];
+                    ks[SL(NSLOT + 1, cb, t)] = v;
+                }
                 if constexpr (TANGENTS) {
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) lp[cb] = __builtin_fmaf(hdr->cout[s], kl[s][cb], lp[cb]);
+                    for (int s = 0; s < NSLOT; ++s) lp[cb] = __builtin_fmaf(hdr->cout[s], kl[s][cb], lp[cb]);
                 }
             }
         }
@@ -709,21 +758,24 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if (flags & 2u) {                          // x += g sqrt(|dt|) z
                 const float gn = hdr->gn;
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    if (!args.noise) {                 // in-kernel noise: a lane's four registers are dimensions 4 qd .. 4 qd + 3
-                        const unsigned long long gs = (unsigned long long)(sample[cb] + args.rng_sample_offset);
-                        uint32_t c[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(hdr->noise_idx + args.rng_noise_base), (uint32_t)qd};
-                        philox4x32_10(c, (uint32_t)args.rng_seed, (uint32_t)(args.rng_seed >> 32));
-                        float z0, z1, z2, z3;
-                        box_muller(c[0], c[1], z0, z1);
-                        box_muller(c[2], c[3], z2, z3);
-                        nz[cb] = f32x4{z0, z1, z2, z3};
-                    }
-                    f32x4 v = ks[((kSlots + 1) * 2 + cb) * 256];
+                for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gn, nz[cb][i], v[i]);
-                    ks[((kSlots + 1) * 2 + cb) * 256] = v;
-                }
+                    for (int t = 0; t < DT; ++t) {
+                        if (!args.noise) {             // in-kernel noise: a lane's four registers of tile t are dimensions 16 t + 4 qd ..
+                            const unsigned long long gs = (unsigned long long)(sample[cb] + args.rng_sample_offset);
+                            uint32_t c[4] = {(uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(hdr->noise_idx + args.rng_noise_base),
+                                             (uint32_t)(4 * t + qd)};
+                            philox4x32_10(c, (uint32_t)args.rng_seed, (uint32_t)(args.rng_seed >> 32));
+                            float z0, z1, z2, z3;
+                            box_muller(c[0], c[1], z0, z1);
+                            box_muller(c[2], c[3], z2, z3);
+                            nz[cb][t] = f32x4{z0, z1, z2, z3};
+                        }
+                        f32x4 v = ks[SL(NSLOT + 1, cb, t)];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(gn, nz[cb][t][i], v[i]);
+                        ks[SL(NSLOT + 1, cb, t)] = v;
+                    }
             }
         }
     }
@@ -751,27 +803,29 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             HdrPtr t0h = (HdrPtr)(args.etab + (size_t)args.n_evals * args.etab_stride);
             HdrPtr t1h = (HdrPtr)(args.etab + (size_t)(args.n_evals + 1) * args.etab_stride);
             const uint32_t use_y = t0h->flags;
-            const f32x4 y0 = ks[((kSlots + 1) * 2 + cb) * 256];
             sfor<kAux>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
                 if (j < args.n_aux) {
                     HdrPtr th = (j < 2) ? t0h : t1h;
-                    float c[kSlots];
+                    float c[NSLOT];
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) c[s] = (j & 1) ? th->cout[s] : th->cin[s];
+                    for (int s = 0; s < NSLOT; ++s) c[s] = (j & 1) ? th->cout[s] : th->cin[s];
                     const float uy = ((use_y >> j) & 1u) ? 1.f : 0.f;
-                    f32x4 v = uy * y0;
 #pragma unroll
-                    for (int s = 0; s < kSlots; ++s) v += c[s] * ks[(s * 2 + cb) * 256];
+                    for (int t = 0; t < DT; ++t) {
+                        f32x4 v = uy * ks[SL(NSLOT + 1, cb, t)];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int d = 4 * qd + i;
-                        if (writer && d < D && args.aux_out[j]) args.aux_out[j][sample[cb] * D + d] = v[i];
+                        for (int s = 0; s < NSLOT; ++s) v += c[s] * ks[SL(s, cb, t)];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int d = 16 * t + 4 * qd + i;
+                            if (writer && d < D && args.aux_out[j]) args.aux_out[j][sample[cb] * D + d] = v[i];
+                        }
                     }
                     if constexpr (TANGENTS) {
                         float part = 0.f;
 #pragma unroll
-                        for (int s = 0; s < kSlots; ++s) part = __builtin_fmaf(c[s], kl[s][cb], part);
+                        for (int s = 0; s < NSLOT; ++s) part = __builtin_fmaf(c[s], kl[s][cb], part);
                         float tot = 0.f;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -784,18 +838,21 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 }
             });
         }
-        const f32x4 xv = ks[((kSlots + 1) * 2 + cb) * 256];
-        if (writer) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int d = 4 * qd + i;
-                if (d < D) {
+        for (int t = 0; t < DT; ++t) {
+            const f32x4 xv = ks[SL(NSLOT + 1, cb, t)];
+            if (writer) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = 16 * t + 4 * qd + i;
+                    if (d < D) {
 #pragma clang fp contract(off)      // x * scale + shift as two roundings, like the reference's torch expression
-                    float v = xv[i];
-                    bad |= (v != v);
-                    if (args.out_scale) v = v * args.out_scale[d];
-                    if (args.out_shift) v = v + args.out_shift[d];
-                    args.x_out[sample[cb] * D + d] = v;
+                        float v = xv[i];
+                        bad |= (v != v);
+                        if (args.out_scale) v = v * args.out_scale[d];
+                        if (args.out_shift) v = v + args.out_shift[d];
+                        args.x_out[sample[cb] * D + d] = v;
+                    }
                 }
             }
         }

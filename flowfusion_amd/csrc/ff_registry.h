@@ -31,6 +31,7 @@ struct SplitKernelEntry {
     int n_hidden;   // hidden layers (compile-time in this family)
     int tangents;   // 1: Hutchinson-capable instantiation (value / tangent column pairs)
     int parts;      // bf16 parts per fp32 operand: 3 (truncation, six products) or 2 (round to nearest, three products)
+    int dt;         // 16-dimension tiles of the state: 1 (dim <= 16, 7 stage slots) or 2 (dim <= 32, 4 stage slots)
     LaunchFn launch;
     const char* name;
 };

@@ -10,8 +10,10 @@
 // parts (six products x two column blocks of 16 samples), 6 with two; a GRANULE = 8 groups, the unit of the LDS pipeline.
 // Stream of one evaluation, in consumption order (width 256: 16 row tiles, 8 k-steps):
 //     layer 1          one k-step (features 0..15 = state dimensions, 16..31 = conditional inputs): for row tile rt
+//                      (dim <= 32: two k-steps -- features 0..31 the state, then 0..15 the conditional inputs)
 //     hidden layer l   for k-step s < 8:  for row tile rt < 16:  group (rt, s)                       l = 1 .. NH-1
 //     output layer     one row tile (the state's 16 dimensions):  for k-step s < 8:  group (0, s)
+//                      (dim <= 32: two row tiles: for k-step s: group (0, s), group (1, s))
 // Behind the stream: the fp32 biases of the hidden->hidden layers [(NH-1)][256] and of the output layer [16] (the
 // first layer's bias travels in the evaluation table as c1_e).
 #pragma once
@@ -38,32 +40,44 @@ FF_HD constexpr int granule_bytes(int parts) { return kFragBytes * parts * kGran
 // input feature held by element j (0..7) of quad q in the fragment of k-step s
 FF_HD constexpr int kidx(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
 
-constexpr int kGroupsL1 = kRowTiles;                  // 16
+// DT = 16-dimension tiles of the state: 1 (dim <= 16: state and conditional inputs share the first layer's single
+// k-step) or 2 (dim <= 32: the first layer takes two k-steps, state then conditional inputs; the output layer two row
+// tiles).  Stage slots kept on chip: 7 (DT = 1: everything up to Dormand-Prince) or 4 (DT = 2: up to the Runge-Kutta
+// 4 schemes and Euler-Maruyama -- the slots of 32 dimensions take twice the LDS).
 constexpr int kGroupsHid = kRowTiles * kKSteps;       // 128
-constexpr int kGroupsOut = kKSteps;                   // 8
-FF_HD constexpr int granules_per_eval(int n_hidden)
+FF_HD constexpr int groups_l1(int dt) { return kRowTiles * dt; }        // 16 / 32
+FF_HD constexpr int groups_out(int dt) { return kKSteps * dt; }         // 8 / 16
+FF_HD constexpr int slots_on_chip(int dt) { return dt == 1 ? 7 : 4; }
+FF_HD constexpr int granules_per_eval(int n_hidden, int dt = 1)
 {
-    return (kGroupsL1 + (n_hidden - 1) * kGroupsHid + kGroupsOut) / kGranuleGroups;
+    return (groups_l1(dt) + (n_hidden - 1) * kGroupsHid + groups_out(dt)) / kGranuleGroups;
 }
-// 4-byte words of the fragment stream / of the whole packed buffer
-FF_HD constexpr size_t stream_words(int n_hidden, int parts) { return (size_t)granules_per_eval(n_hidden) * (granule_bytes(parts) / 4); }
-FF_HD constexpr size_t total_words(int n_hidden, int parts) { return stream_words(n_hidden, parts) + (size_t)(n_hidden - 1) * kWidth + 16; }
+// 4-byte words of the fragment stream / of the whole packed buffer (behind the stream: the hidden->hidden biases and the
+// 16 dt output biases)
+FF_HD constexpr size_t stream_words(int n_hidden, int parts, int dt = 1)
+{
+    return (size_t)granules_per_eval(n_hidden, dt) * (granule_bytes(parts) / 4);
+}
+FF_HD constexpr size_t total_words(int n_hidden, int parts, int dt = 1)
+{
+    return stream_words(n_hidden, parts, dt) + (size_t)(n_hidden - 1) * kWidth + 16 * dt;
+}
 
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
     int wbuf;    // kBuffers weight granules (24 KiB each with three parts, 16 KiB with two)
-    int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (kSlots + 2) x 2 x 256 threads x 16 B
+    int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (slots + 2) x 2 column blocks x dt x 256 threads x 16 B
     int c1;      // 2 x H floats: first-layer bias of the current / next evaluation
     int hbias;   // (NH-1) x H floats + 16: hidden->hidden and output biases
     int zero;    // H floats of zeros (what tangent columns read instead of a bias)
     int total;
 };
-FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts)
+FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts, int dt = 1)
 {
     LdsMap m{};
     m.wbuf = 0;
     m.slots = kBuffers * granule_bytes(parts);
-    m.c1 = m.slots + (7 + 2) * 2 * 256 * 16;
+    m.c1 = m.slots + (slots_on_chip(dt) + 2) * 2 * dt * 256 * 16;
     m.hbias = m.c1 + 2 * H * 4;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
     m.zero = m.hbias + nh1 * H * 4 + H * 4;      // (one spare vector: a tile read of the 16-float output bias stays inside)

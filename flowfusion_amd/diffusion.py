@@ -178,7 +178,7 @@ class ScoreModel(nn.Module):
         attribute that can be flipped later) selects the arithmetic of the Linear layers in the fused solves:
         ``"f32"`` (default) is exact fp32, what the reference computes; ``"bf16x3"`` runs them on the bf16 matrix cores
         with every operand split into three bf16 parts and six products per term -- fp32-class accuracy (1e-7
-        relative per layer) at about twice the speed, for SiLU networks up to 256 wide, dim <= 16 (state-only and
+        relative per layer) at about twice the speed, for SiLU networks up to 256 wide, dim <= 16 (``"bf16x2"``: <= 32) (state-only and
         Hutchinson solves, fixed grids and the adaptive methods, ``sample_sde``); anything else -- the exact trace, the
         Hutch++ / XTrace estimators -- raises with this setting.  ``"bf16x2"``: two bf16 parts by
         round-to-nearest (operands to 16 significand bits, unbiased) and three products per term -- half the matrix
@@ -347,6 +347,7 @@ class ScoreModel(nn.Module):
 
     def _ode_table(self, t_span, method, options, mode):
         plan = solvers.plan_ode(t_span, method, options)
+        self._net().require_slots(int(plan.slot.max()) + 1, mode, f"method={method!r}")
         a, b, c1, _ = self._schedule(plan.t_eval, "ode")
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
 

@@ -111,6 +111,7 @@ class _FlowBase(nn.Module):
 
     def _table(self, t_span, method, options, mode):
         plan = solvers.plan_ode(t_span, method, options)
+        self._net().require_slots(int(plan.slot.max()) + 1, mode, f"method={method!r}")
         a, b, c1 = self._schedule(plan.t_eval)
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
 

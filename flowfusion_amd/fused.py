@@ -234,6 +234,7 @@ class FusedNet:
 
         def step(y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux):
             n = int(t_rows.numel())
+            self.require_slots(int(slots.max()) + 1, mode, "this adaptive method")
             a, b, c1 = schedule(sign * t_rows)
             rows = torch.zeros(n + 2, 32 + width, dtype=torch.float32)
             rows[:n, 0] = sign * a
@@ -261,3 +262,16 @@ class FusedNet:
 
     def width(self, mode: int = MODE_STATE) -> int:
         return int(self.plan(mode).width)
+
+    def stage_slots(self, mode: int = MODE_STATE) -> int:
+        """Runge-Kutta stage slots the selected kernel keeps on chip: 7 (FF_MAX_SLOTS) everywhere except the split-precision
+        kernels for states of 17-32 dimensions, which keep 4 (csrc/ff_split_layout.h slots_on_chip)."""
+        plan = self.plan(mode)
+        return 4 if (plan.precision != _native.PREC_F32 and plan.dregs == 16) else 7
+
+    def require_slots(self, used: int, mode: int, what: str):
+        if used > self.stage_slots(mode):
+            raise NotImplementedError(
+                f"precision={self.precision!r} with {self.dim} state dimensions keeps {self.stage_slots(mode)} Runge-Kutta stage "
+                f"slots on chip and {what} needs {used}: use euler / midpoint / heun3 / rk4 / rk4_classic (or bosh3 / fehlberg2 "
+                "/ adaptive_heun), or precision='f32'")

@@ -298,6 +298,81 @@ def test_split_euler_maruyama(prec, built_library):
     assert _native.kernel_name(sm._net().plan(0)).startswith("mlp_ode_split")
 
 
+WIDE_STATE = {
+    "c5_32d_c8_ve_4x256": (32, 8, [256] * 4, "VESDE", False, "rk4", 25, 300),
+    "d20_subvp_ragged": (20, 0, [100, 200], "SUBVPSDE", False, "heun3", 20, 129),
+    "d17_c16_vp_one_layer": (17, 16, [256], "VPSDE", True, "euler", 40, 97),
+    "d31_c3_six_layers": (31, 3, [128] * 6, "VPSDE", False, "rk4_classic", 10, 65),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(WIDE_STATE))
+def test_split_states_of_17_to_32_dimensions(name, built_library):
+    """precision="bf16x2" for states of 17-32 dimensions (BASELINE config 5's shape included): two k-steps in the first
+    layer (state, then conditional inputs), two row tiles in the output layer, four stage slots on chip.  Sampling,
+    Hutchinson log-density and Euler-Maruyama (injected stream; in-kernel noise against the numpy Philox restatement and
+    across launch cuts) against the oracle at the family's tolerances; methods with more than four stages raise."""
+    from tests._philox import normals
+    Dm, C, units, sde_name, no_sigma, method, nsteps, B = WIDE_STATE[name]
+    sm, so32, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 41, "bf16x2")
+    assert "_d2_" in _native.kernel_name(sm._net().plan(0)) and sm._net().stage_slots(0) == 4
+    torch.manual_seed(77)
+    base = torch.randn(B, Dm) * (float(sm.sde.sigma_max) if hasattr(sm.sde, "sigma_max") else 1.0)
+    cond = torch.randn(B, C) if C else None
+    cd = None if cond is None else cond.to(DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+    z = base / (float(sm.sde.sigma_max) if hasattr(sm.sde, "sigma_max") else 1.0)
+    got, _ = sm.sample_ode_from_base(z.to(DEV), conditional=cd, method=method, options=opts)
+    ref64 = so64.sample_ode_from_base(z.double(), None if cond is None else cond.double(), method, opts).float()
+    assert _state_err(got, ref64) < STATE_TOL, name
+    sm.hutch = True
+    x0 = torch.randn(min(B, 64), Dm) * 0.8
+    cl = None if cond is None else cond[:x0.shape[0]]
+    torch.manual_seed(5)
+    lp = sm.log_prob(x0.to(DEV), conditional=None if cl is None else cl.to(DEV), method=method, options=opts)
+    ref = so64.log_prob(x0.double(), None if cl is None else cl.double(), method, opts, "hutch", sm.e.cpu().double()).float()
+    assert _logp_err(lp, ref) < LOGP_TOL, name
+    sm.hutch = False
+    steps = 30
+    draws = [torch.randn(B, Dm) for _ in range(steps)]
+    it = iter(draws)
+    em = sm._sample_sde_from(base.to(DEV), lambda like: next(it).to(DEV), cd, steps)
+    assert _state_err(em, so32.sample_sde(base, draws, cond, steps=steps)) < STATE_TOL, name
+    seed, off = 1357, 90
+    a = sm._sample_sde_from(base.to(DEV), None, cd, 9, rng=(seed, off))
+    zz = torch.from_numpy(normals(seed, off, B, Dm, list(range(9))))
+    it = iter(zz)
+    b = sm._sample_sde_from(base.to(DEV), lambda like: next(it).to(DEV), cd, 9)
+    assert _state_err(a, b.cpu()) < STATE_TOL
+    cut = B // 3
+    parts = [sm._sample_sde_from(base[lo:hi].to(DEV), None, None if cd is None else cd[lo:hi], 9, rng=(seed, off + lo))
+             for lo, hi in ((0, cut), (cut, B))]
+    assert torch.equal(torch.cat(parts), a)
+    with pytest.raises(NotImplementedError, match="stage"):
+        sm.sample_ode_from_base(z.to(DEV), conditional=cd, method="dopri5_fixed", options=opts)
+    with pytest.raises(NotImplementedError, match="stage"):
+        sm.sample_ode_from_base(z.to(DEV), conditional=cd)                  # adaptive dopri5: seven slots
+    # an embedded pair that fits the four slots (bosh3: four with its FSAL stage; on the random sub-VP / VP networks of the
+    # other cases bosh3 meets a non-finite error estimate with the f32 kernels as well: fehlberg2 there)
+    am = "bosh3" if name.startswith("c5") else "fehlberg2"
+
+    def adaptive(prec):
+        sm.precision = prec
+        try:
+            return sm.sample_ode_from_base(z.to(DEV), conditional=cd, method=am, atol=1e-6, rtol=1e-6)[0], dict(sm.last_solver_stats)
+        except RuntimeError as e:              # random stiff networks: a non-finite error estimate stops torchdiffeq the same way
+            return str(e), None
+    x32, st32 = adaptive("f32")
+    xb, stb = adaptive("bf16x2")
+    if isinstance(x32, str):
+        assert isinstance(xb, str) and ("underflow" in xb or "non-finite" in xb), (x32, xb)
+    else:
+        assert stb == st32                                               # the same accept / reject sequence
+        rb = so64.sample_ode_from_base(z.double(), None if cond is None else cond.double(), am, None, atol=1e-6, rtol=1e-6).float()
+        assert _state_err(xb, rb) < 2e-4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("B", [1, 31, 32, 33, 127, 128, 129, 1000])
