@@ -195,6 +195,14 @@ def extra_configs(device):
                        Be, "log-probs/s", wall, name_of(net, 2), kms, (DIM + 1) * 2.0 * mac_per_eval(DIM, UNITS) * tab2.shape[0] * Be,
                        {"launches": len(passes), "note": "kernel_ms sums the launches; columns carried: "
                         + " + ".join(f"(1+{c})" for _, c in passes) + f" for {DIM}+1 needed"}))
+    # the same exact-trace call on the opt-in 16-bit-operand kernels (a value column + unit tangents per column block of 16)
+    sm.precision = "bf16x2"
+    sm.log_prob(xe[:64].contiguous(), method="rk4", options=opts)
+    _, wall2, kms2 = _timed(lambda: sm.log_prob(xe, method="rk4", options=opts), device)
+    out.append({"workload": "the exact-trace log_prob above on precision='bf16x2' (opt-in)", "value": Be / wall2, "unit": "log-probs/s",
+                "wall_ms": 1e3 * wall2, "kernel": _native.kernel_name(sm._net().plan(2)), "kernel_ms": kms2,
+                "dtype": "bf16x2-split, f32 accumulate", "speedup_vs_f32_entry": out[-1]["wall_ms"] / (1e3 * wall2)})
+    sm.precision = "f32"
     # --- small batches: one solve of config 2 at 4096 samples (latency-bound: 256 tiles for 1024 SIMDs) -----------------
     # default dispatch = the cooperative twin (a tile per workgroup); FF_COOP=0 pins the one-wavefront kernel
     sm.hutch = False

@@ -187,8 +187,8 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
             f"precision='{name}' (one of the split-precision options 'bf16x3' / 'bf16x2') has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
             f"activation={act[0]}: the split-precision family covers SiLU networks of 1-6 hidden layers up to 256 wide, "
             "dim <= 16 (bf16x2: <= 32 with at most 4 Runge-Kutta stages), cond_dim <= 16, state-only (Euler-Maruyama included) and "
-            "Hutchinson solves, fixed grids and the adaptive "
-            "methods; no exact trace; use precision='f32'")
+            "Hutchinson / exact-trace solves, fixed grids and the adaptive "
+            "methods; use precision='f32'")
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "

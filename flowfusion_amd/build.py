@@ -83,8 +83,9 @@ def _wide_name(tile, h, d, c, t) -> str:
 
 # split-precision family (width 256): (hidden layers, TANGENTS, bf16 parts per operand: 3 = FF_PREC_BF16X3, 2 = FF_PREC_BF16X2)
 # ... and 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32, two-part kernels only)
-SPLIT_INSTANCES = [(nh, t, parts, 1) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1)] + \
-                  [(nh, t, 2, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1)]
+# TANGENTS here: 0 state only, 1 Hutchinson column pairs, 2 exact trace (value column + unit tangents)
+SPLIT_INSTANCES = [(nh, t, parts, 1) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
+                  [(nh, t, 2, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)]
 
 
 def _split_name(nh, t, parts=3, dt=1) -> str:
@@ -206,7 +207,7 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
 namespace ff {{
 int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
 {{
-    auto kern = split::mlp_ode_split_kernel<{nh}, {'true' if t else 'false'}, {parts}, {dt}>;
+    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}>;
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);

@@ -48,7 +48,7 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
     if (!plan || !hidden_widths || dim < 1 || cond_dim < 0 || n_hidden < 1) return FF_ERR_BADARG;
     if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH && mode != FF_MODE_EXACT) return FF_ERR_BADARG;
     if (activation < 0 || activation >= FF_ACT_COUNT) return FF_ERR_BADARG;
-    if (activation != FF_ACT_SILU || mode == FF_MODE_EXACT || dim > 32 || cond_dim > 16) return FF_ERR_UNSUPPORTED;
+    if (activation != FF_ACT_SILU || dim > 32 || cond_dim > 16) return FF_ERR_UNSUPPORTED;
     const int need_dt = dim > 16 ? 2 : 1;              // 16-dimension tiles of the state
     int wmax = 0;
     for (int i = 0; i < n_hidden; ++i) {
@@ -56,7 +56,7 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
         if (hidden_widths[i] > wmax) wmax = hidden_widths[i];
     }
     if (wmax > ff::split::kWidth) return FF_ERR_UNSUPPORTED;
-    const int need_t = mode != FF_MODE_STATE;
+    const int need_t = mode == FF_MODE_STATE ? 0 : (mode == FF_MODE_HUTCH ? 1 : 2);
     int best = -1;
     for (int i = 0; i < ff::g_n_split_kernels; ++i) {
         const ff::SplitKernelEntry& k = ff::g_split_kernels[i];
@@ -71,7 +71,7 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
     plan->dregs = 8 * need_dt;                         // 4 dimensions x 2 column blocks per lane and 16-dimension tile
     plan->cregs = cond_dim > 0 ? 8 : 0;
     plan->kernel_id = best;
-    plan->tile = 32;
+    plan->tile = need_t == 2 ? 16 : 32;                // exact trace: a sample and its unit tangents share a column block of 16
     plan->activation = FF_ACT_SILU;
     plan->precision = precision;
     return FF_OK;
@@ -143,7 +143,8 @@ static bool plan_ok_split(const ff_mlp_plan_t* p)
         p->kernel_id >= ff::g_n_split_kernels)
         return false;
     const ff::SplitKernelEntry& k = ff::g_split_kernels[p->kernel_id];
-    return k.parts == split_parts(p->precision) && p->width == ff::split::kWidth && p->tile == 32 && p->dregs == 8 * k.dt &&
+    return k.parts == split_parts(p->precision) && p->width == ff::split::kWidth && p->tile == (k.tangents == 2 ? 16 : 32) &&
+           p->dregs == 8 * k.dt &&
            p->cregs == (p->cond_dim > 0 ? 8 : 0) &&
            p->n_hidden == k.n_hidden && p->activation == FF_ACT_SILU && p->dim >= 1 && p->dim <= 16 * k.dt &&
            p->cond_dim >= 0 && p->cond_dim <= 16;
@@ -349,8 +350,11 @@ extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, co
 extern "C" int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode)
 {
     if (plan_ok_split(plan)) {
-        if (mode != FF_MODE_STATE && mode != FF_MODE_HUTCH) return FF_ERR_BADARG;
-        return mode == FF_MODE_STATE ? 128 : 64;
+        const int kt = ff::g_split_kernels[plan->kernel_id].tangents;
+        if (mode == FF_MODE_STATE && kt == 0) return 128;
+        if (mode == FF_MODE_HUTCH && kt == 1) return 64;
+        if (mode == FF_MODE_EXACT && kt == 2) return 8 * (16 / (1 + (plan->dim < 15 ? plan->dim : 15)));
+        return FF_ERR_BADARG;
     }
     if (!plan_ok(plan)) return FF_ERR_BADARG;
     int nt, unit;
@@ -366,9 +370,18 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     if (!a->x_in || !a->x_out || !a->wpack || !a->etab || a->batch < 0 || a->n_evals < 0) return FF_ERR_BADARG;
     if (plan->cond_dim > 0 && !a->cond) return FF_ERR_BADARG;
     const ff::SplitKernelEntry& k = ff::g_split_kernels[plan->kernel_id];
-    if (a->mode != FF_MODE_STATE && a->mode != FF_MODE_HUTCH) return a->mode == FF_MODE_EXACT ? FF_ERR_UNSUPPORTED : FF_ERR_BADARG;
-    if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
-    if (a->mode == FF_MODE_HUTCH && (!a->probe || !a->dlogp_out)) return FF_ERR_BADARG;
+    if (a->mode != FF_MODE_STATE && a->mode != FF_MODE_HUTCH && a->mode != FF_MODE_EXACT) return FF_ERR_BADARG;
+    if (k.tangents != (a->mode == FF_MODE_STATE ? 0 : (a->mode == FF_MODE_HUTCH ? 1 : 2))) return FF_ERR_BADARG;
+    if (a->mode == FF_MODE_HUTCH && !a->probe) return FF_ERR_BADARG;
+    if (a->mode != FF_MODE_STATE && !a->dlogp_out) return FF_ERR_BADARG;
+    int nt = k.tangents == 1 ? 1 : 0, tfirst = 0;
+    if (a->mode == FF_MODE_EXACT) {                     // unit tangents of dimensions [tfirst, tfirst + nt): at most 15 per launch
+        nt = plan->dim < 15 ? plan->dim : 15;
+        tfirst = a->tangent_first;
+        if (a->tangent_count > 0) nt = a->tangent_count;
+        else if (plan->dim > nt) return FF_ERR_BADARG;      // must be split by the caller
+        if (tfirst < 0 || tfirst + nt > plan->dim || nt + 1 > 16) return FF_ERR_BADARG;
+    }
     // what this family does not carry: the Jacobian output; noise rows with tangent columns
     if (a->jac_out || (a->noise && k.tangents)) return FF_ERR_UNSUPPORTED;
     if (a->noise && a->noise_stride < a->batch * (int64_t)plan->dim) return FF_ERR_BADARG;
@@ -385,11 +398,11 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.rng_seed = a->rng_seed; ka.rng_sample_offset = a->rng_sample_offset; ka.rng_noise_base = a->rng_noise_base;
     for (int j = 0; j < FF_MAX_AUX; ++j) { ka.aux_out[j] = a->aux_out[j]; ka.aux_lp_out[j] = a->aux_lp_out[j]; }
     ka.n_evals = a->n_evals; ka.n_hidden = plan->n_hidden; ka.dim = plan->dim; ka.cond_dim = plan->cond_dim;
-    ka.n_tangent = k.tangents ? 1 : 0;
+    ka.n_tangent = nt; ka.unit_tangents = a->mode == FF_MODE_EXACT ? 1 : 0; ka.tangent_first = tfirst;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     ka.wpack_floats = (int)ff::split::total_words(k.n_hidden, k.parts, k.dt);
-    const long long spw = k.tangents ? 64 : 128;
+    const long long spw = k.tangents == 0 ? 128 : (k.tangents == 1 ? 64 : 8 * (16 / (1 + nt)));
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
     const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden, k.parts, k.dt).total;

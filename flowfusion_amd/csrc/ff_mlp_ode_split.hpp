@@ -135,10 +135,15 @@ FF_HD constexpr int micro_op(bool tangents, int parts, int j)
     if (j < 7 + nv) return tangents ? M_TV_H + (j - 7) : M_VALUE;
     return (parts == 3 ? M_TOPH : M_RHI) + (j - 7 - nv);
 }
-template <bool TANGENTS, int NP, int J>
-__device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u, u32x4 (&frag)[NP], int word, bool is_tangent)
+// TM: 0 = no tangent columns, 1 = (value, tangent) column pairs (Hutchinson: the slope comes from the neighbour lane by
+// DPP), 2 = a value column followed by up to 15 unit-tangent columns (exact trace: the slope comes from lane `vsrc / 4`
+// through the LDS crossbar, ds_bpermute)
+template <int TM, int NP, int J>
+__device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u, u32x4 (&frag)[NP], int word, bool is_tangent,
+                                           int vsrc)
 {
     constexpr float NLOG2E = -1.44269504088896340736f;
+    constexpr bool TANGENTS = TM != 0;
     constexpr int OP = micro_op(TANGENTS, NP, J);
 #ifdef FF_SPLIT_SKIP_OPS        // timing experiments only: bit OP set = that micro-op is left out (wrong results)
     if constexpr (((FF_SPLIT_SKIP_OPS) >> OP) & 1) return;
@@ -174,8 +179,13 @@ __device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u,
         u.t0 = u.o0 + u.t0;
         u.t1 = u.o1 + u.t1;
     } else if constexpr (OP == M_TV_DPP) {     // tangent lanes: the slope of their sample's value column
-        u.t0 = from_value_lane(u.t0);
-        u.t1 = from_value_lane(u.t1);
+        if constexpr (TM == 1) {
+            u.t0 = from_value_lane(u.t0);
+            u.t1 = from_value_lane(u.t1);
+        } else {
+            u.t0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vsrc, __builtin_bit_cast(int, u.t0)));
+            u.t1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(vsrc, __builtin_bit_cast(int, u.t1)));
+        }
     } else if constexpr (OP == M_TV_MUL) {
         u.o0 = u.a0 * u.t0;
         u.o1 = u.a1 * u.t1;
@@ -286,9 +296,11 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
 // straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
 // accumulator registers at every control-flow join).
-template <int NH, bool TANGENTS, int NP = 3, int DT = 1>
+template <int NH, int TM, int NP = 3, int DT = 1>
 __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
+    static_assert(TM >= 0 && TM <= 2, "0: state only, 1: Hutchinson column pairs, 2: exact trace (unit tangents)");
+    constexpr bool TANGENTS = TM != 0;
     static_assert(NP == 2 || NP == 3, "two (round-to-nearest) or three (truncation) bf16 parts per operand");
     static_assert(DT == 1 || (DT == 2 && NP == 2), "states of up to 32 dimensions: two-part kernels only (LDS)");
     constexpr int NSLOT = slots_on_chip(DT);           // stage slots kept in LDS: 7 / 4
@@ -314,15 +326,28 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     long long sample[2];
     bool live[2];
     bool is_tangent = false;
+    int role = 0;                                      // 0: value column; j > 0: the j-th tangent column of its sample
+    int vsrc = 0;                                      // byte index (lane * 4) of the sample's value lane in this lane's quad row
+    const int NT = TM == 2 ? args.n_tangent : (TM == 1 ? 1 : 0);   // tangent columns per sample
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        if constexpr (TANGENTS) {
+        if constexpr (TM == 1) {
             sample[cb] = wave * 16 + cb * 8 + (col >> 1);
             is_tangent = (col & 1) != 0;
+            role = col & 1;
+            live[cb] = sample[cb] < args.batch;
+        } else if constexpr (TM == 2) {
+            // a column block of 16 holds floor(16 / (1 + NT)) samples, each a value column and its NT unit tangents
+            const int per = 1 + NT, spb = 16 / per, sb = col / per;
+            role = col - sb * per;
+            is_tangent = role > 0;
+            vsrc = ((lane & 0x30) | (col - role)) * 4;
+            sample[cb] = (wave * 2 + cb) * spb + sb;
+            live[cb] = sb < spb && sample[cb] < args.batch;
         } else {
             sample[cb] = wave * 32 + cb * 16 + col;
+            live[cb] = sample[cb] < args.batch;
         }
-        live[cb] = sample[cb] < args.batch;
         if (!live[cb]) sample[cb] = args.batch - 1;
     }
 
@@ -349,6 +374,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                         if (args.in_shift) v = v - args.in_shift[d];
                         if (args.in_scale) v = v / args.in_scale[d];
                         xv[i] = v;
+                    } else if constexpr (TM == 2) {
+                        xv[i] = (d == args.tangent_first + role - 1) ? 1.f : 0.f;      // unit tangent e_j
                     } else {
                         xv[i] = args.probe[sample[cb] * D + d];
                     }
@@ -408,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 ks[SL(0, cb, t)] = v;
             }
             if constexpr (TANGENTS) {
-                if (args.kl1_in && is_tangent && qd == 0) kl[0][cb] = args.kl1_in[sample[cb]];
+                if (args.kl1_in && role == 1 && qd == 0) kl[0][cb] = args.kl1_in[sample[cb]];
             }
         }
     }
@@ -564,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 constexpr int U = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.unit[G][K] : GapPlans<TANGENTS, NP>::k1.unit[G][K];
                 constexpr int J = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.micro[G][K] : GapPlans<TANGENTS, NP>::k1.micro[G][K];
                 constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
-                unit_micro<TANGENTS, NP, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent);
+                unit_micro<TM, NP, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent, vsrc);
             }
         });
     };
@@ -589,8 +616,8 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                         sfor<8>([&](auto uu) {
                             constexpr int U = decltype(uu)::value;
                             constexpr int cb = U >> 2, word = U & 3, prt = 2 * (s + 1) + (word >> 1), r0 = 2 * (word & 1);
-                            unit_micro<TANGENTS, NP, decltype(jj)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
-                                                                         bf[(s + 1) & 1][cb], word, is_tangent);
+                            unit_micro<TM, NP, decltype(jj)::value>(P[prt][cb][r0], P[prt][cb][r0 + 1], us[U],
+                                                                   bf[(s + 1) & 1][cb], word, is_tangent, vsrc);
                         });
                     });
                 }
@@ -786,14 +813,20 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const bool writer = live[cb] && !is_tangent;
-        if constexpr (TANGENTS) {
-            // the sample's divergence = sum over the four quads of its tangent column (the next lane)
+        // a sample's divergence = sum over the four quads of its tangent columns (the NT lanes after its value lane)
+        auto reduce_tangents = [&](float part) __attribute__((always_inline)) {
             float tot = 0.f;
+            for (int j = 1; j <= NT; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int src = ((g << 4) | ((col + 1) & 15)) * 4;
-                tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, lp[cb])));
+                for (int g = 0; g < 4; ++g) {
+                    const int src = ((g << 4) | ((col + j) & 15)) * 4;
+                    tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, part)));
+                }
             }
+            return tot;
+        };
+        if constexpr (TANGENTS) {
+            const float tot = reduce_tangents(lp[cb]);
             if (writer && qd == 0 && args.dlogp_out)
                 args.dlogp_out[sample[cb]] = (args.dlogp_in ? args.dlogp_in[sample[cb]] : 0.f) + tot;
         }
@@ -826,12 +859,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                         float part = 0.f;
 #pragma unroll
                         for (int s = 0; s < NSLOT; ++s) part = __builtin_fmaf(c[s], kl[s][cb], part);
-                        float tot = 0.f;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int src = ((g << 4) | ((col + 1) & 15)) * 4;
-                            tot += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, part)));
-                        }
+                        const float tot = reduce_tangents(part);
                         if (writer && qd == 0 && args.aux_lp_out[j])
                             args.aux_lp_out[j][sample[cb]] = uy * (args.dlogp_in ? args.dlogp_in[sample[cb]] : 0.f) + tot;
                     }

@@ -29,7 +29,7 @@ extern const int g_n_kernels;
 // split-precision family (FF_PREC_BF16X3 / FF_PREC_BF16X2, ff_mlp_ode_split.hpp): width <= 256, dim <= 16, cond <= 16
 struct SplitKernelEntry {
     int n_hidden;   // hidden layers (compile-time in this family)
-    int tangents;   // 1: Hutchinson-capable instantiation (value / tangent column pairs)
+    int tangents;   // 0: state only; 1: Hutchinson (value / tangent column pairs); 2: exact trace (a value column + unit tangents)
     int parts;      // bf16 parts per fp32 operand: 3 (truncation, six products) or 2 (round to nearest, three products)
     int dt;         // 16-dimension tiles of the state: 1 (dim <= 16, 7 stage slots) or 2 (dim <= 32, 4 stage slots)
     LaunchFn launch;

@@ -179,8 +179,8 @@ class ScoreModel(nn.Module):
         ``"f32"`` (default) is exact fp32, what the reference computes; ``"bf16x3"`` runs them on the bf16 matrix cores
         with every operand split into three bf16 parts and six products per term -- fp32-class accuracy (1e-7
         relative per layer) at about twice the speed, for SiLU networks up to 256 wide, dim <= 16 (``"bf16x2"``: <= 32) (state-only and
-        Hutchinson solves, fixed grids and the adaptive methods, ``sample_sde``); anything else -- the exact trace, the
-        Hutch++ / XTrace estimators -- raises with this setting.  ``"bf16x2"``: two bf16 parts by
+        Hutchinson solves and the exact trace, fixed grids and the adaptive methods, ``sample_sde``); anything else -- the
+        Hutch++ / XTrace estimators, other activations, wider networks -- raises with this setting.  ``"bf16x2"``: two bf16 parts by
         round-to-nearest (operands to 16 significand bits, unbiased) and three products per term -- half the matrix
         work of ``"bf16x3"``; a layer's error is ~4e-7 relative in the mean (fp32: 2e-8), end to end the sampler and
         the log-density of the headline configuration stay at the fp32 kernel's distance from the float64 oracle."""
@@ -611,6 +611,9 @@ class ScoreModel(nn.Module):
         the right-hand side and its whole Jacobian -- instead of in a single launch.  Probes are drawn once per
         solve on the state's device, as the reference does (:703-719)."""
         net = self._net()
+        if net.precision != "f32":
+            raise NotImplementedError(f"precision={net.precision!r}: the Hutch++ / XTrace estimators need the Jacobian output of the "
+                                      "f32 kernels (bf16x3 / bf16x2 serve hutchinson=True and the exact trace)")
         if not x0.is_cuda:
             raise RuntimeError("flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
                                f"(got a tensor on {x0.device}); there is no CPU fallback")

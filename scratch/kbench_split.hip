@@ -57,7 +57,7 @@ int main(int argc, char** argv)
     ff::KernelArgs a; memset(&a, 0, sizeof(a));
     a.x_in = dx; a.x_out = dy; a.wpack = dw; a.etab = dt; a.batch = B; a.n_evals = n_evals; a.n_hidden = NH; a.dim = D;
     a.etab_stride = stride; a.wpack_floats = (int)nw; a.debug_stamps = dbg;
-    auto kern = mlp_ode_split_kernel<NH, false, NP>;
+    auto kern = mlp_ode_split_kernel<NH, 0, NP>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const unsigned lds = (unsigned)lds_map(H, NH, NP).total;
     const unsigned grid = (unsigned)((B + 127) / 128);

@@ -133,7 +133,9 @@ def test_split_precision_scope_and_errors(built_library):
     mk = lambda **kw: _native.make_plan(kw.get("dim", 16), kw.get("cond", 0), kw.get("hidden", [256] * 4), kw.get("mode", MODE_STATE),
                                         kw.get("act", (_native.ACT_SILU, 0.0, 0.0)), _native.PREC_BF16X3)
     assert mk().precision == 1
-    for bad in (dict(dim=17), dict(cond=17), dict(hidden=[300, 300]), dict(hidden=[64] * 7), dict(mode=MODE_EXACT),
+    px = mk(mode=MODE_EXACT)
+    assert (px.tile, _native.kernel_name(px)) == (16, "mlp_ode_split_h256_n4_t2") and _native.samples_per_workgroup(px, MODE_EXACT) == 8
+    for bad in (dict(dim=17), dict(cond=17), dict(hidden=[300, 300]), dict(hidden=[64] * 7),
                 dict(act=(_native.ACT_TANH, 0.0, 0.0))):
         with pytest.raises(NotImplementedError, match="bf16x3"):
             mk(**bad)
@@ -298,6 +300,53 @@ def test_split_euler_maruyama(prec, built_library):
     assert _native.kernel_name(sm._net().plan(0)).startswith("mlp_ode_split")
 
 
+EXACT = {
+    "d2_ve_notebook": (2, 0, [128] * 3, "VESDE", False, "rk4", 20, 200),            # 3 columns per sample: 5 samples per block
+    "d7_c3_subvp": (7, 3, [200, 64], "SUBVPSDE", False, "heun3", 15, 77),           # 8 columns: 2 samples per block
+    "d16_vp_4x256": (16, 0, [256] * 4, "VPSDE", True, "rk4", 25, 100),              # 17 columns: passes of 15 + 1 tangents
+    "d15_c16_one_layer": (15, 16, [256], "VPSDE", True, "euler", 30, 45),           # 16 columns: one sample per block
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("name", list(EXACT))
+def test_split_exact_trace(name, prec, built_library):
+    """The reference's default divergence (exact trace, diffusion.py:483-503) on the split kernels: a value column and its
+    unit-tangent columns share a column block of 16, the slope travels through the LDS crossbar; fixed grid against the
+    float64 oracle's autograd trace, and the reference's DEFAULT call (adaptive dopri5 + exact trace) against the f32
+    kernels' (same accept / reject sequence)."""
+    Dm, C, units, sde_name, no_sigma, method, nsteps, B = EXACT[name]
+    sm, so32, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 57, prec)
+    assert _native.kernel_name(sm._net().plan(MODE_EXACT)).endswith("_t2")
+    torch.manual_seed(8)
+    x0 = torch.randn(B, Dm) * 0.7
+    cond = torch.randn(B, C) if C else None
+    cd = None if cond is None else cond.to(DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+    lp = sm.log_prob(x0.to(DEV), conditional=cd, method=method, options=opts)
+    ref = so64.log_prob(x0.double(), None if cond is None else cond.double(), method, opts, "exact").float()
+    assert lp.shape == (B, 1) and _logp_err(lp, ref) < LOGP_TOL, name
+    lpd = sm.log_prob(x0[:40].to(DEV), conditional=None if cd is None else cd[:40])      # dopri5, exact trace, min_step 1e-6
+    stats = dict(sm.last_solver_stats)
+    sm.precision = "f32"
+    lp32 = sm.log_prob(x0[:40].to(DEV), conditional=None if cd is None else cd[:40])
+    # the same controller on fp32-class right-hand sides: the same steps, give or take an attempt whose error ratio sat at 1
+    assert abs(sm.last_solver_stats["attempts"] - stats["attempts"]) <= 2 and _logp_err(lpd, lp32.cpu()) < 2e-4
+
+
+@pytest.mark.gpu
+def test_split_exact_trace_wide_state(built_library):
+    """bf16x2, 20 dimensions: the trace in passes of 15 + 5 unit tangents on the two-tile kernels."""
+    sm, _, so64 = _seeded(20, 2, [128, 128], "VPSDE", True, 61, "bf16x2")
+    assert "_d2_" in _native.kernel_name(sm._net().plan(MODE_EXACT))
+    torch.manual_seed(3)
+    x0, cond = torch.randn(50, 20) * 0.7, torch.randn(50, 2)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 12}
+    lp = sm.log_prob(x0.to(DEV), conditional=cond.to(DEV), method="rk4", options=opts)
+    assert _logp_err(lp, so64.log_prob(x0.double(), cond.double(), "rk4", opts, "exact").float()) < LOGP_TOL
+
+
 WIDE_STATE = {
     "c5_32d_c8_ve_4x256": (32, 8, [256] * 4, "VESDE", False, "rk4", 25, 300),
     "d20_subvp_ragged": (20, 0, [100, 200], "SUBVPSDE", False, "heun3", 20, 129),
@@ -412,8 +461,8 @@ def test_split_flows_and_wrappers(prec, built_library):
     assert _logp_err(lp, lp32.cpu()) < LOGP_TOL
     # what the family does not do raises instead of switching arithmetic silently
     f.precision = prec
-    with pytest.raises(NotImplementedError, match="bf16x3"):
-        f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)           # exact trace
+    lpe = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts)         # exact trace: 16 unit tangents, two passes
+    assert _logp_err(lpe, fo64.log_prob(x.double(), cond[:48].double(), "rk4", opts).float()) < LOGP_TOL
     # the reference's default call -- adaptive dopri5, one launch per attempted step -- on the split kernels
     ga = f.sample(xT.to(DEV), cond.to(DEV))
     assert _state_err(ga, fo64.sample(xT.double(), cond.double(), "dopri5", None, atol=1e-9, rtol=1e-7).float()) < 2e-4
