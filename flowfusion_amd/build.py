@@ -84,12 +84,14 @@ def _wide_name(tile, h, d, c, t) -> str:
 # split-precision family (width 256): (hidden layers, TANGENTS, bf16 parts per operand: 3 = FF_PREC_BF16X3, 2 = FF_PREC_BF16X2)
 # ... and 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32, two-part kernels only)
 # TANGENTS here: 0 state only, 1 Hutchinson column pairs, 2 exact trace (value column + unit tangents)
-SPLIT_INSTANCES = [(nh, t, parts, 1) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
-                  [(nh, t, 2, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)]
+# ... and the on-chip width: 256, or 128 for networks up to 128 wide (1-4 hidden layers: the reference's demo sizes)
+SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
+                  [(nh, t, 2, 2, 256) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
+                  [(nh, t, parts, dt, 128) for (parts, dt) in ((3, 1), (2, 1), (2, 2)) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 
 
-def _split_name(nh, t, parts=3, dt=1) -> str:
-    return f"mlp_ode_split{'' if parts == 3 else parts}_h256{'' if dt == 1 else '_d' + str(dt)}_n{nh}_t{t}"
+def _split_name(nh, t, parts=3, dt=1, width=256) -> str:
+    return f"mlp_ode_split{'' if parts == 3 else parts}_h{width}{'' if dt == 1 else '_d' + str(dt)}_n{nh}_t{t}"
 
 
 def _has_coop(h, act=0) -> bool:
@@ -198,8 +200,8 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
         if not p.exists() or p.read_text() != src:
             p.write_text(src)
         files.append(p)
-    for nh, t, parts, dt in SPLIT_INSTANCES:
-        name = _split_name(nh, t, parts, dt)
+    for nh, t, parts, dt, width in SPLIT_INSTANCES:
+        name = _split_name(nh, t, parts, dt, width)
         src = f"""// generated by flowfusion_amd/build.py -- do not edit
 #include <atomic>
 #include "ff_registry.h"
@@ -207,7 +209,7 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
 namespace ff {{
 int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
 {{
-    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}>;
+    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}, {width}>;
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
@@ -263,7 +265,7 @@ int launch_{name}_coop(const KernelArgs* a, unsigned grid, unsigned lds, hipStre
         [f"int launch_{_split_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in SPLIT_INSTANCES]
     )
     split_rows = ",\n".join(
-        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, launch_{_split_name(*i)}, "{_split_name(*i)}"}}' for i in SPLIT_INSTANCES
+        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, launch_{_split_name(*i)}, "{_split_name(*i)}"}}' for i in SPLIT_INSTANCES
     )
     rows = ",\n".join(
         f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, {i[7]}, launch_{_inst_name(*i)}, "{_inst_name(*i)}", '

@@ -57,17 +57,19 @@ static int plan_split(int dim, int cond_dim, int n_hidden, const int* hidden_wid
     }
     if (wmax > ff::split::kWidth) return FF_ERR_UNSUPPORTED;
     const int need_t = mode == FF_MODE_STATE ? 0 : (mode == FF_MODE_HUTCH ? 1 : 2);
-    int best = -1;
+    int best = -1;                                     // the narrowest instantiation that holds the network
     for (int i = 0; i < ff::g_n_split_kernels; ++i) {
         const ff::SplitKernelEntry& k = ff::g_split_kernels[i];
-        if (k.n_hidden == n_hidden && k.tangents == need_t && k.parts == split_parts(precision) && k.dt == need_dt) best = i;
+        if (k.n_hidden == n_hidden && k.tangents == need_t && k.parts == split_parts(precision) && k.dt == need_dt &&
+            k.width >= wmax && (best < 0 || k.width < ff::g_split_kernels[best].width))
+            best = i;
     }
     if (best < 0) return FF_ERR_UNSUPPORTED;
     memset(plan, 0, sizeof(*plan));
     plan->dim = dim;
     plan->cond_dim = cond_dim;
     plan->n_hidden = n_hidden;
-    plan->width = ff::split::kWidth;
+    plan->width = ff::g_split_kernels[best].width;
     plan->dregs = 8 * need_dt;                         // 4 dimensions x 2 column blocks per lane and 16-dimension tile
     plan->cregs = cond_dim > 0 ? 8 : 0;
     plan->kernel_id = best;
@@ -143,7 +145,7 @@ static bool plan_ok_split(const ff_mlp_plan_t* p)
         p->kernel_id >= ff::g_n_split_kernels)
         return false;
     const ff::SplitKernelEntry& k = ff::g_split_kernels[p->kernel_id];
-    return k.parts == split_parts(p->precision) && p->width == ff::split::kWidth && p->tile == (k.tangents == 2 ? 16 : 32) &&
+    return k.parts == split_parts(p->precision) && p->width == k.width && p->tile == (k.tangents == 2 ? 16 : 32) &&
            p->dregs == 8 * k.dt &&
            p->cregs == (p->cond_dim > 0 ? 8 : 0) &&
            p->n_hidden == k.n_hidden && p->activation == FF_ACT_SILU && p->dim >= 1 && p->dim <= 16 * k.dt &&
@@ -176,7 +178,7 @@ extern "C" const char* ff_plan_kernel_name(const ff_mlp_plan_t* plan)
 extern "C" size_t ff_mlp_wpack_floats(const ff_mlp_plan_t* plan)
 {
     if (plan_ok_split(plan)) {
-        return ff::split::total_words(plan->n_hidden, split_parts(plan->precision), plan->dregs / 8);
+        return ff::split::total_words(plan->n_hidden, split_parts(plan->precision), plan->dregs / 8, plan->width);
     }
     if (!plan_ok(plan)) return 0;
     return plan_layout(plan).total_floats;
@@ -215,7 +217,8 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
     const int D = plan->dim, C = plan->cond_dim, H = plan->width, NH = plan->n_hidden;
     const int NP = split_parts(plan->precision), DT = plan->dregs / 8;
     uint32_t* words = (uint32_t*)out;
-    memset(out, 0, sp::total_words(NH, NP, DT) * 4);
+    const int NR = sp::row_tiles(H), NS = sp::ksteps(H);
+    memset(out, 0, sp::total_words(NH, NP, DT, H) * 4);
     size_t group = 0;                                  // running group index in the stream
     // one group: fragments [hi, mid, lo] of 16-row tile rt; element (quad q, j) multiplies input column col(q, j)
     auto put_group = [&](const float* Wl, int rows, int ld, int rt, auto col) {
@@ -241,7 +244,7 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
     // layer 1: ONE k-step -- features 0..15 the state dimensions, 16..31 the conditional inputs; states of up to 32
     // dimensions: TWO k-steps -- features 0..31 the state, then 0..15 the conditional inputs
     for (int s1 = 0; s1 < DT; ++s1)
-        for (int rt = 0; rt < sp::kRowTiles; ++rt)
+        for (int rt = 0; rt < NR; ++rt)
             put_group(W[0], hidden_widths[0], in_features0, rt, [&](int q, int j) {
                 const int f = sp::kidx(0, q, j);
                 if (DT == 1) return f < 16 ? (f < D ? x_col0 + f : -1) : (f - 16 < C ? c_col0 + f - 16 : -1);
@@ -250,28 +253,28 @@ static int wpack_split(const ff_mlp_plan_t* plan, const float* const* W, const f
     // hidden -> hidden, k-major: k-step s, row tile rt
     for (int l = 1; l < NH; ++l) {
         const int win = hidden_widths[l - 1], wout = hidden_widths[l];
-        for (int s = 0; s < sp::kKSteps; ++s)
-            for (int rt = 0; rt < sp::kRowTiles; ++rt)
+        for (int s = 0; s < NS; ++s)
+            for (int rt = 0; rt < NR; ++rt)
                 put_group(W[l], wout, win, rt, [&](int q, int j) {
                     const int kk = sp::kidx(s, q, j);
                     return kk < win ? kk : -1;
                 });
-        float* bo = out + sp::stream_words(NH, NP, DT) + (size_t)(l - 1) * H;
+        float* bo = out + sp::stream_words(NH, NP, DT, H) + (size_t)(l - 1) * H;
         for (int row = 0; row < wout; ++row) bo[row] = b[l][row];
     }
     // output layer: DT row tiles (the state's dimensions), k-major
     {
         const int win = hidden_widths[NH - 1];
-        for (int s = 0; s < sp::kKSteps; ++s)
+        for (int s = 0; s < NS; ++s)
             for (int t = 0; t < DT; ++t)
                 put_group(W[NH], D, win, t, [&](int q, int j) {
                     const int kk = sp::kidx(s, q, j);
                     return kk < win ? kk : -1;
                 });
-        float* bo = out + sp::stream_words(NH, NP, DT) + (size_t)(NH - 1) * H;
+        float* bo = out + sp::stream_words(NH, NP, DT, H) + (size_t)(NH - 1) * H;
         for (int row = 0; row < D; ++row) bo[row] = b[NH][row];
     }
-    return group == (size_t)sp::granules_per_eval(NH, DT) * sp::kGranuleGroups ? FF_OK : FF_ERR_BADARG;
+    return group == (size_t)sp::granules_per_eval(NH, DT, H) * sp::granule_groups(H) ? FF_OK : FF_ERR_BADARG;
 }
 
 extern "C" int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* const* b,
@@ -401,7 +404,7 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     ka.n_tangent = nt; ka.unit_tangents = a->mode == FF_MODE_EXACT ? 1 : 0; ka.tangent_first = tfirst;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
-    ka.wpack_floats = (int)ff::split::total_words(k.n_hidden, k.parts, k.dt);
+    ka.wpack_floats = (int)ff::split::total_words(k.n_hidden, k.parts, k.dt, k.width);
     const long long spw = k.tangents == 0 ? 128 : (k.tangents == 1 ? 64 : 8 * (16 / (1 + nt)));
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;

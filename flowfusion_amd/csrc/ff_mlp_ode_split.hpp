@@ -228,15 +228,20 @@ __device__ __forceinline__ void unit_micro(float pre0, float pre1, UnitState& u,
 // instruction before it), the gaps that carry an LDS-DMA hold none, and a gap holds as few micro-ops as the span's room
 // allows (one with three parts; up to two with two parts, whose k-steps are half as long).  Units of span kind 1 read
 // row tiles 0 and 1 of the span's OWN output, complete after groups 0 and 1: they start behind group 1.
-constexpr int kMaxSpanGaps = 16 * 12, kMaxPerGap = 3;
+constexpr int kMaxSpanGaps = 16 * 12, kMaxPerGap = 5;
 #ifndef FF_SPLIT_SPACING
 #define FF_SPLIT_SPACING 2
 #endif
 constexpr int kMicroSpacing = FF_SPLIT_SPACING;      // gaps between consecutive micro-ops of a unit
 FF_HD constexpr int gaps_per_group(int parts) { return 2 * products_of(parts); }
-// gap i of a group that opens a granule issues one of the wavefront's 2 * parts LDS-DMAs
-FF_HD constexpr bool dma_gap(int parts, int i) { return parts == 3 ? (i % 2 == 0) : (i < 4); }
+// gap i of a group that opens a granule issues one of the wavefront's `ndma` LDS-DMAs (its quarter of the granule:
+// parts * granule_groups / 4 fragments -- 6 / 4 at width 256, 3 / 2 at width 128)
+FF_HD constexpr int dma_count(int parts, int w) { return parts * granule_groups(w) / 4; }
 FF_HD constexpr int dma_index(int parts, int i) { return parts == 3 ? i / 2 : i; }
+FF_HD constexpr bool dma_gap(int parts, int w, int i)
+{
+    return (parts == 3 ? (i % 2 == 0) : true) && dma_index(parts, i) < dma_count(parts, w);
+}
 // gap i of a group reads fragment `part` of the group kAhead on from LDS (-1: none)
 FF_HD constexpr int read_part(int parts, int i) { return parts == 3 ? (i % 4 == 1 ? i / 4 : -1) : (i == 1 ? 0 : (i == 4 ? 1 : -1)); }
 struct GapPlan {
@@ -245,14 +250,14 @@ struct GapPlan {
     signed char micro[kMaxSpanGaps][kMaxPerGap];
     bool ok;
 };
-FF_HD constexpr GapPlan make_gap_plan(bool tangents, int parts, int first_gap)
+FF_HD constexpr GapPlan make_gap_plan(bool tangents, int parts, int first_gap, int w)
 {
     GapPlan p{};
-    const int per = gaps_per_group(parts), span = 16 * per, nm = micro_count(tangents, parts);
+    const int per = gaps_per_group(parts), span = row_tiles(w) * per, nm = micro_count(tangents, parts);
     bool dma[kMaxSpanGaps] = {};
     int room = 0;
     for (int g = 0; g < span; ++g) {
-        dma[g] = ((g / per) % kGranuleGroups == 0) && dma_gap(parts, g % per);
+        dma[g] = ((g / per) % granule_groups(w) == 0) && dma_gap(parts, w, g % per);
         room += (g >= first_gap && !dma[g]) ? 1 : 0;
     }
     const int cap = (8 * nm + room - 1) / room;
@@ -279,10 +284,10 @@ FF_HD constexpr GapPlan make_gap_plan(bool tangents, int parts, int first_gap)
     }
     return p;
 }
-template <bool TANGENTS, int NP>
+template <bool TANGENTS, int NP, int HW>
 struct GapPlans {
-    static constexpr GapPlan k0 = make_gap_plan(TANGENTS, NP, 0);
-    static constexpr GapPlan k1 = make_gap_plan(TANGENTS, NP, 2 * gaps_per_group(NP));
+    static constexpr GapPlan k0 = make_gap_plan(TANGENTS, NP, 0, HW);
+    static constexpr GapPlan k1 = make_gap_plan(TANGENTS, NP, 2 * gaps_per_group(NP), HW);
     static_assert(k0.ok && k1.ok, "the activation micro-ops of a k-step do not fit behind its MFMAs");
 };
 
@@ -296,20 +301,22 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
 // straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
 // accumulator registers at every control-flow join).
-template <int NH, int TM, int NP = 3, int DT = 1>
+template <int NH, int TM, int NP = 3, int DT = 1, int HW = 256>
 __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
+    static_assert(HW == 256 || HW == 128, "on-chip width: 256 or 128");
     static_assert(TM >= 0 && TM <= 2, "0: state only, 1: Hutchinson column pairs, 2: exact trace (unit tangents)");
     constexpr bool TANGENTS = TM != 0;
     static_assert(NP == 2 || NP == 3, "two (round-to-nearest) or three (truncation) bf16 parts per operand");
     static_assert(DT == 1 || (DT == 2 && NP == 2), "states of up to 32 dimensions: two-part kernels only (LDS)");
     constexpr int NSLOT = slots_on_chip(DT);           // stage slots kept in LDS: 7 / 4
-    constexpr int NR = kRowTiles;                      // 16 row tiles of 16 rows: width 256
-    constexpr int NS = kKSteps;                        // 8 k-steps of 32 features
-    constexpr int H = 16 * NR;
-    constexpr int GB = granule_bytes(NP);              // 24 KiB (three parts) / 16 KiB (two)
+    constexpr int NR = row_tiles(HW);                  // row tiles of 16 rows: 16 (width 256) / 8
+    constexpr int NS = ksteps(HW);                     // k-steps of 32 features: 8 / 4
+    constexpr int H = HW;
+    constexpr int GRG = granule_groups(HW);            // groups per granule: 8 / 4
+    constexpr int GB = granule_bytes(NP, HW);          // 24 KiB (three parts) / 16 KiB (two) at width 256, half that at 128
     constexpr int GG = gaps_per_group(NP);             // MFMAs of a group: 12 / 6
-    constexpr int NDMA = 2 * NP;                       // fragments of a granule this wavefront fetches: 6 / 4
+    constexpr int NDMA = dma_count(NP, HW);            // fragments of a granule this wavefront fetches
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             for (int t = 0; t < DT; ++t) ks[SL(s, cb, t)] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
-        const float* bsrc = args.wpack + (size_t)stream_words(NH, NP, DT);
+        const float* bsrc = args.wpack + (size_t)stream_words(NH, NP, DT, HW);
         const int nb = (NH - 1) * H + 16 * DT;
         for (int i = threadIdx.x; i < nb; i += 256) ((float*)(lds + M.hbias))[i] = bsrc[i];
     }
@@ -456,13 +463,15 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 
     // ---- weight pipeline state (all wave-uniform) -----------------------------------------------------------------
     const unsigned char* const wbase = (const unsigned char*)args.wpack;
-    const long long wbytes = (long long)granules_per_eval(NH, DT) * GB;
+    const long long wbytes = (long long)granules_per_eval(NH, DT, HW) * GB;
     long long dpos = 0;                                // byte position in the stream of the NEXT granule to fetch
     unsigned rbuf = 0;                                 // LDS byte offset of the buffer the current granule is read from
     const int my_frag = wv * NDMA * 1024;              // this wavefront's quarter of a granule
     auto fetch_c1 = [&](int e) __attribute__((always_inline)) {      // c1 of evaluation e -> its LDS buffer (every wavefront issues
         const int ee_ = e < args.n_evals ? e : 0;                      // the same 1 KiB copy: equal VMEM counts keep the counted waits uniform)
-        dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32), lane16);
+        // (width 128: a row holds 512 bytes of c1 -- the upper lanes re-read its last 16 bytes instead of the next row)
+        dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32),
+                     lane16 < H * 4 - 16 ? lane16 : H * 4 - 16);
     };
     fetch_c1(0);
     for (int g = 0; g < 2; ++g) {                      // granules 0 and 1 into buffers 0 and 1
@@ -520,11 +529,13 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             dpos += GB;
             if (dpos >= wbytes) dpos = 0;
         }
-        if constexpr (GQ == kGranuleGroups - kAhead) {
+        if constexpr (GQ == GRG - kAhead) {
             // everything but the NDMA DMAs issued in this granule has landed, and this wavefront's reads of the current
             // buffer have returned: after the barrier the next granule is visible to all and the previous buffer is free
-            if constexpr (NP == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if constexpr (NDMA == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
 #ifndef FF_SPLIT_NOBARRIER       // timing experiment only (with FF_SPLIT_NODMA)
             __builtin_amdgcn_s_barrier();
 #endif
@@ -545,11 +556,11 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             if constexpr (part >= 0) {
 #endif
                 constexpr int T = GQ + kAhead;                          // fragments of the group kAhead groups on
-                if constexpr (T >= kGranuleGroups) wq[kAhead][part] = *(const u32x4*)(lds + wa_next + ((T - kGranuleGroups) * NP + part) * 1024);
+                if constexpr (T >= GRG) wq[kAhead][part] = *(const u32x4*)(lds + wa_next + ((T - GRG) * NP + part) * 1024);
                 else wq[kAhead][part] = *(const u32x4*)(lds + wa + (T * NP + part) * 1024);
             }
 #ifndef FF_SPLIT_NODMA           // timing experiment only: never refresh the weight buffers (wrong results)
-            if constexpr (GQ == 0 && dma_gap(NP, I))
+            if constexpr (GQ == 0 && dma_gap(NP, HW, I))
                 dma_fragment(ddst + dma_index(NP, I) * 1024, dsrc + dma_index(NP, I) * 1024, lane16);
 #endif
             fill(ii);
@@ -562,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         for (int a = 0; a < kAhead; ++a)
 #pragma unroll
             for (int p = 0; p < NP; ++p) wq[a][p] = wq[a + 1][p];
-        if constexpr (GQ == kGranuleGroups - 1) wa = wa_next;
+        if constexpr (GQ == GRG - 1) wa = wa_next;
     };
     auto no_fill = [](auto) {};
 
@@ -586,10 +597,10 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
         constexpr int KIND = decltype(kind)::value, G = decltype(gg)::value, sn = decltype(snn)::value;
         sfor<kMaxPerGap>([&](auto kk) {
             constexpr int K = decltype(kk)::value;
-            constexpr int N = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.n[G] : GapPlans<TANGENTS, NP>::k1.n[G];
+            constexpr int N = KIND == 0 ? GapPlans<TANGENTS, NP, HW>::k0.n[G] : GapPlans<TANGENTS, NP, HW>::k1.n[G];
             if constexpr (K < N) {
-                constexpr int U = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.unit[G][K] : GapPlans<TANGENTS, NP>::k1.unit[G][K];
-                constexpr int J = KIND == 0 ? GapPlans<TANGENTS, NP>::k0.micro[G][K] : GapPlans<TANGENTS, NP>::k1.micro[G][K];
+                constexpr int U = KIND == 0 ? GapPlans<TANGENTS, NP, HW>::k0.unit[G][K] : GapPlans<TANGENTS, NP, HW>::k1.unit[G][K];
+                constexpr int J = KIND == 0 ? GapPlans<TANGENTS, NP, HW>::k0.micro[G][K] : GapPlans<TANGENTS, NP, HW>::k1.micro[G][K];
                 constexpr int cb = U >> 2, word = U & 3, rt = 2 * sn + (word >> 1), r0 = 2 * (word & 1);
                 unit_micro<TM, NP, J>(T[rt][cb][r0], T[rt][cb][r0 + 1], us[U], dst[cb], word, is_tangent, vsrc);
             }
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
                 // interleaved so that eight independent chains cover each other's latencies
                 sfor<DT>([&](auto tt) {
                     constexpr int t = decltype(tt)::value;
-                    group(std::integral_constant<int, (s * DT + t) % 8>{}, O[t], bf[s & 1], no_fill);
+                    group(std::integral_constant<int, (s * DT + t) % GRG>{}, O[t], bf[s & 1], no_fill);
                 });
                 if constexpr (s < NS - 1) {
                     sfor<micro_count(TANGENTS, NP)>([&](auto jj) {
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
 #ifdef FF_SPLIT_STAMP_GROUPS    // diagnostic: a stamp per group of k-step 3 (every hidden layer)
                     if constexpr (s == 3) FF_STAMP();
 #endif
-                    group(std::integral_constant<int, rt % 8>{}, Cc[rt], bf[s & 1], [&](auto ii) {
+                    group(std::integral_constant<int, rt % GRG>{}, Cc[rt], bf[s & 1], [&](auto ii) {
                         constexpr int G = rt * GG + decltype(ii)::value;
 #ifdef FF_SPLIT_STAMP_GAPS      // diagnostic: a stamp behind every MFMA of groups 0 and 1 of k-step 3
                         if constexpr (s == 3 && rt < 2) FF_STAMP();
@@ -702,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
             constexpr int k1 = decltype(kk)::value;                      // k-step of the first layer
             sfor<NR>([&](auto tt) {
                 constexpr int rt = decltype(tt)::value;
-                group(std::integral_constant<int, rt % 8>{}, A[rt], yf[k1], [&](auto ii) {
+                group(std::integral_constant<int, rt % GRG>{}, A[rt], yf[k1], [&](auto ii) {
                     constexpr int I = decltype(ii)::value;
                     if constexpr (k1 == 0 && rt == 0 && I == GG - 1) fetch_c1(e + 1);     // (after the weight DMAs of this granule)
                     // last k-step: row tiles 0, 1 are complete after groups 0, 1: their activation rides on the other 14

@@ -32,6 +32,7 @@ struct SplitKernelEntry {
     int tangents;   // 0: state only; 1: Hutchinson (value / tangent column pairs); 2: exact trace (a value column + unit tangents)
     int parts;      // bf16 parts per fp32 operand: 3 (truncation, six products) or 2 (round to nearest, three products)
     int dt;         // 16-dimension tiles of the state: 1 (dim <= 16, 7 stage slots) or 2 (dim <= 32, 4 stage slots)
+    int width;      // on-chip layer width: 256 or 128
     LaunchFn launch;
     const char* name;
 };

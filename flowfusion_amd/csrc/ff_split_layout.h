@@ -24,18 +24,21 @@
 namespace ff {
 namespace split {
 
-constexpr int kRowTiles = 16;         // 16-row tiles of a 256-wide layer
-constexpr int kKSteps = 8;            // 32-feature k-steps of a 256-wide layer
-constexpr int kWidth = 256;
+constexpr int kWidth = 256;           // widest network of the family
 constexpr int kFragBytes = 1024;
-constexpr int kGranuleGroups = 8;
 constexpr int kBuffers = 3;
+
+// WIDTH of the on-chip layers: 256 (16 row tiles of 16 rows, 8 k-steps of 32 features) or 128 (8 row tiles, 4 k-steps:
+// networks up to 128 wide -- the reference's demo sizes -- do a quarter of the matrix work of the 256-wide kernels).
+FF_HD constexpr int row_tiles(int w) { return w / 16; }
+FF_HD constexpr int ksteps(int w) { return w / 32; }
+FF_HD constexpr int granule_groups(int w) { return w >= 256 ? 8 : 4; }     // groups per granule: layer boundaries stay granule-aligned
 
 // PARTS = bf16 parts per fp32 operand: 3 (FF_PREC_BF16X3: hi / mid / lo by truncation, exact; six products per term) or
 // 2 (FF_PREC_BF16X2: hi / mid by round-to-nearest, 16 significand bits; three products per term).  A group carries
-// `parts` fragments, a granule 8 groups.
+// `parts` fragments.
 FF_HD constexpr int products_of(int parts) { return parts == 3 ? 6 : 3; }
-FF_HD constexpr int granule_bytes(int parts) { return kFragBytes * parts * kGranuleGroups; }      // 24 KiB / 16 KiB
+FF_HD constexpr int granule_bytes(int parts, int w = kWidth) { return kFragBytes * parts * granule_groups(w); }   // 24 / 16 KiB at width 256
 
 // input feature held by element j (0..7) of quad q in the fragment of k-step s
 FF_HD constexpr int kidx(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 4 * q + (j & 3); }
@@ -44,31 +47,31 @@ FF_HD constexpr int kidx(int s, int q, int j) { return 32 * s + 16 * (j >> 2) + 
 // k-step) or 2 (dim <= 32: the first layer takes two k-steps, state then conditional inputs; the output layer two row
 // tiles).  Stage slots kept on chip: 7 (DT = 1: everything up to Dormand-Prince) or 4 (DT = 2: up to the Runge-Kutta
 // 4 schemes and Euler-Maruyama -- the slots of 32 dimensions take twice the LDS).
-constexpr int kGroupsHid = kRowTiles * kKSteps;       // 128
-FF_HD constexpr int groups_l1(int dt) { return kRowTiles * dt; }        // 16 / 32
-FF_HD constexpr int groups_out(int dt) { return kKSteps * dt; }         // 8 / 16
+FF_HD constexpr int groups_hid(int w = kWidth) { return row_tiles(w) * ksteps(w); }            // 128 / 32
+FF_HD constexpr int groups_l1(int dt, int w = kWidth) { return row_tiles(w) * dt; }             // 16 / 32 (width 256)
+FF_HD constexpr int groups_out(int dt, int w = kWidth) { return ksteps(w) * dt; }               // 8 / 16 (width 256)
 FF_HD constexpr int slots_on_chip(int dt) { return dt == 1 ? 7 : 4; }
-FF_HD constexpr int granules_per_eval(int n_hidden, int dt = 1)
+FF_HD constexpr int granules_per_eval(int n_hidden, int dt = 1, int w = kWidth)
 {
-    return (groups_l1(dt) + (n_hidden - 1) * kGroupsHid + groups_out(dt)) / kGranuleGroups;
+    return (groups_l1(dt, w) + (n_hidden - 1) * groups_hid(w) + groups_out(dt, w)) / granule_groups(w);
 }
 // 4-byte words of the fragment stream / of the whole packed buffer (behind the stream: the hidden->hidden biases and the
 // 16 dt output biases)
-FF_HD constexpr size_t stream_words(int n_hidden, int parts, int dt = 1)
+FF_HD constexpr size_t stream_words(int n_hidden, int parts, int dt = 1, int w = kWidth)
 {
-    return (size_t)granules_per_eval(n_hidden, dt) * (granule_bytes(parts) / 4);
+    return (size_t)granules_per_eval(n_hidden, dt, w) * (granule_bytes(parts, w) / 4);
 }
-FF_HD constexpr size_t total_words(int n_hidden, int parts, int dt = 1)
+FF_HD constexpr size_t total_words(int n_hidden, int parts, int dt = 1, int w = kWidth)
 {
-    return stream_words(n_hidden, parts, dt) + (size_t)(n_hidden - 1) * kWidth + 16 * dt;
+    return stream_words(n_hidden, parts, dt, w) + (size_t)(n_hidden - 1) * w + 16 * dt;
 }
 
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
-    int wbuf;    // kBuffers weight granules (24 KiB each with three parts, 16 KiB with two)
+    int wbuf;    // kBuffers weight granules
     int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (slots + 2) x 2 column blocks x dt x 256 threads x 16 B
-    int c1;      // 2 x H floats: first-layer bias of the current / next evaluation
-    int hbias;   // (NH-1) x H floats + 16: hidden->hidden and output biases
+    int c1;      // 2 x 1 KiB: first-layer bias of the current / next evaluation (one LDS-DMA fragment each)
+    int hbias;   // (NH-1) x H floats + 16 dt: hidden->hidden and output biases
     int zero;    // H floats of zeros (what tangent columns read instead of a bias)
     int total;
 };
@@ -76,12 +79,12 @@ FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts, int dt = 1)
 {
     LdsMap m{};
     m.wbuf = 0;
-    m.slots = kBuffers * granule_bytes(parts);
+    m.slots = kBuffers * granule_bytes(parts, H);
     m.c1 = m.slots + (slots_on_chip(dt) + 2) * 2 * dt * 256 * 16;
-    m.hbias = m.c1 + 2 * H * 4;
+    m.hbias = m.c1 + 2 * 1024;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
-    m.zero = m.hbias + nh1 * H * 4 + H * 4;      // (one spare vector: a tile read of the 16-float output bias stays inside)
-    m.total = m.zero + H * 4;
+    m.zero = m.hbias + nh1 * H * 4 + 256 * 4;    // (a spare KiB: a tile read of the 16 dt output biases stays inside)
+    m.total = m.zero + 256 * 4;
     return m;
 }
 

@@ -81,7 +81,7 @@ extern "C" {
  *                   2^-24 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32: fp32-class
  *                   accuracy (error ~1e-7 relative to sum |w||x|, like an fp32 dot product) at the bf16 matrix
  *                   rate.  SiLU networks up to 256 wide, dim <= 16, cond_dim <= 16; every mode, noise rows and the
- *                   adaptive-step fields of ff_ode_args (not jac_out); see DESIGN.md section 3.2.
+ *                   adaptive-step fields of the launch arguments, jac_out excepted; see DESIGN.md section 3.2.
  *   FF_PREC_BF16X2  opt-in: two bf16 parts by round-to-nearest (hi + mid = the operand to 16 significand bits) and
  *                   the three products hi.hi, hi.mid, mid.hi: operands rounded to 2^-17 relative (TF32 keeps 2^-11),
  *                   unbiased, fp32 accumulation; error of a 256-term layer ~4e-7 relative to sum |w||x| in the mean

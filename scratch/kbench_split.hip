@@ -59,7 +59,7 @@ int main(int argc, char** argv)
     a.etab_stride = stride; a.wpack_floats = (int)nw; a.debug_stamps = dbg;
     auto kern = mlp_ode_split_kernel<NH, 0, NP>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const unsigned lds = (unsigned)lds_map(H, NH, NP).total;
+    const unsigned lds = (unsigned)lds_map(H, NH, NP).total;   // (width 256)
     const unsigned grid = (unsigned)((B + 127) / 128);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a); CK(hipDeviceSynchronize());
