@@ -505,3 +505,57 @@ def test_split_full_size_properties_and_speed(prec, built_library):
     print(f"\n[split] 2^20 x 100-step RK4: {prec} {t_split * 1e3:.1f} ms ({B / t_split:.3g} samples/s), "
           f"f32 {t_f32 * 1e3:.1f} ms ({B / t_f32:.3g} samples/s), speed-up {t_f32 / t_split:.2f}x")
     assert t_split < 0.8 * t_f32
+
+
+@pytest.mark.gpu
+def test_split_random_shapes_against_oracle(built_library):
+    """Seeded sweep over what the split-precision family is compiled for -- both options, on-chip widths 128 and 256, states
+    of 1-32 dimensions (bf16x2 beyond 16), 0-16 conditional inputs, 1-6 ragged hidden layers, the three SDEs, fixed-grid
+    methods within the kernel's stage slots, batch sizes around the tile sizes -- sampling, Hutchinson / exact-trace
+    log-density and Euler-Maruyama against the float64 oracle, so that every (width, state tiles, mode, parts) instance is
+    reached by some case."""
+    import random
+    rnd = random.Random(777)
+    kernels = set()
+    for case in range(40):
+        prec = rnd.choice(PRECS)
+        wmax = rnd.choice([24, 64, 100, 128, 129, 200, 256])
+        depth = rnd.choice([1, 2, 3, 4, 6])
+        units = [rnd.randint(max(8, wmax // 2), wmax) for _ in range(depth)]
+        units[rnd.randrange(depth)] = wmax
+        Dm = rnd.choice([1, 2, 3, 8, 15, 16] + ([17, 20, 31, 32] if prec == "bf16x2" else []))
+        C = rnd.choice([0, 0, 1, 5, 16])
+        sde_name = rnd.choice(["VPSDE", "VESDE", "SUBVPSDE"])
+        no_sigma = rnd.random() < 0.5
+        method, nsteps = rnd.choice([("euler", 12), ("midpoint", 8), ("rk4", 6), ("heun3", 6), ("rk4_classic", 5)] +
+                                    ([("dopri5_fixed", 4)] if Dm <= 16 else []))
+        B = rnd.choice([1, 7, 31, 33, 64, 130])
+        sm, _, so64 = _seeded(Dm, C, units, sde_name, no_sigma, 3000 + case, prec)
+        torch.manual_seed(5000 + case)
+        z = torch.randn(B, Dm)
+        cond = torch.randn(B, C) if C else None
+        cd = None if cond is None else cond.to(DEV)
+        c64 = None if cond is None else cond.double()
+        opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / nsteps}
+        tag = (case, prec, Dm, C, units, sde_name, no_sigma, method, B)
+        x0, _ = sm.sample_ode_from_base(z.to(DEV), conditional=cd, method=method, options=opts)
+        assert _state_err(x0, so64.sample_ode_from_base(z.double(), c64, method, opts).float()) < STATE_TOL, tag
+        kernels.add(_native.kernel_name(sm._net().plan(0)))
+        mode = rnd.choice(["hutch", "exact"])
+        sm.hutch = mode == "hutch"
+        xd = torch.randn(B, Dm) * 0.5
+        lp = sm.log_prob(xd.to(DEV), conditional=cd, method=method, options=opts)
+        e = sm.e.cpu().double() if sm.hutch else None
+        assert _logp_err(lp, so64.log_prob(xd.double(), c64, method, opts, mode, e).float()) < LOGP_TOL, tag + (mode,)
+        kernels.add(_native.kernel_name(sm._net().plan(1 if sm.hutch else 2)))
+        sm.hutch = False
+        if case % 4 == 0:
+            prior = torch.randn(B, Dm) * (float(sm.sde.sigma_max) if hasattr(sm.sde, "sigma_max") else 1.0)
+            draws = [torch.randn(B, Dm) for _ in range(10)]
+            it = iter(draws)
+            em = sm._sample_sde_from(prior.to(DEV), lambda like: next(it).to(DEV), cd, 10)
+            so32 = score_oracle(dict(D=Dm, C=C, E=8, units=units, sde=sde_name, sde_kw={}, no_sigma=no_sigma),
+                                {k: v.detach().cpu().clone() for k, v in sm.state_dict().items()})
+            assert _state_err(em, so32.sample_sde(prior, draws, cond, steps=10)) < STATE_TOL, tag + ("em",)
+    assert all(any(f"_h{w}" in k for k in kernels) for w in (128, 256)) and any("_d2_" in k for k in kernels), sorted(kernels)
+    assert len(kernels) >= 24, sorted(kernels)
