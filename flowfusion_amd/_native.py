@@ -81,7 +81,7 @@ class OdeArgs(ctypes.Structure):
         ("rng_sample_offset", ctypes.c_int64),
         ("jac_out", ctypes.c_void_p),
         ("jac_all", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("stage_slots", ctypes.c_int32),
     ]
 
 
@@ -321,12 +321,18 @@ _PLAN_WORDS = ctypes.sizeof(PlanStruct) // 4
 
 
 def _plan_from_words(words: List[int]) -> PlanStruct:
-    return PlanStruct.from_buffer_copy((ctypes.c_int32 * _PLAN_WORDS)(*words))
+    return PlanStruct.from_buffer_copy((ctypes.c_int32 * _PLAN_WORDS)(*words[:_PLAN_WORDS]))
 
 
-def plan_words(plan: PlanStruct) -> List[int]:
-    """The plan as 32-bit words (how it travels through the custom op's integer-list argument)."""
-    return list((ctypes.c_int32 * _PLAN_WORDS).from_buffer_copy(plan))
+def _slots_hint(words: List[int]) -> int:
+    """ff_ode_args.stage_slots travelling behind the plan's words (0 = unknown)."""
+    return int(words[_PLAN_WORDS]) if len(words) > _PLAN_WORDS else 0
+
+
+def plan_words(plan: PlanStruct, stage_slots: int = 0) -> List[int]:
+    """The plan as 32-bit words (how it travels through the custom op's integer-list argument), followed by the number of
+    stage slots the launch's table uses (ff_ode_args.stage_slots; 0 = unknown)."""
+    return list((ctypes.c_int32 * _PLAN_WORDS).from_buffer_copy(plan)) + [int(stage_slots)]
 
 
 def _chk(t: Optional[torch.Tensor], name: str, dev) -> int:
@@ -385,6 +391,7 @@ def mlp_ode(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[torch
     a.rng_seed = rng_seed & 0xFFFFFFFFFFFFFFFF
     a.rng_sample_offset = rng_sample_offset
     a.rng_noise_base = rng_noise_base
+    a.stage_slots = _slots_hint(plan)
     if cond is not None and tuple(cond.shape) != (B, p.cond_dim):
         raise RuntimeError(f"cond has shape {tuple(cond.shape)}, expected {(B, p.cond_dim)}")
     if probe is not None and tuple(probe.shape) != (B, D):
@@ -447,6 +454,7 @@ def mlp_ode_step(x: torch.Tensor, cond: Optional[torch.Tensor], probe: Optional[
         a.aux_out[j] = aux[j].data_ptr()
         a.aux_lp_out[j] = aux_lp[j].data_ptr() if mode != MODE_STATE else 0
     a.n_aux = n_aux
+    a.stage_slots = _slots_hint(plan)
     if etab.shape[1] != 32 + p.width or a.n_evals < 0:
         raise RuntimeError("evaluation table does not match the plan")
     with torch.cuda.device(dev):

@@ -90,6 +90,11 @@ SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3
                   [(nh, t, parts, dt, 128) for (parts, dt) in ((3, 1), (2, 1), (2, 2)) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 
 
+def _has_four_slot_twin(inst) -> bool:
+    """128-wide two-part kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU)."""
+    return inst[2] == 2 and inst[3] == 1 and inst[4] == 128
+
+
 def _split_name(nh, t, parts=3, dt=1, width=256) -> str:
     return f"mlp_ode_split{'' if parts == 3 else parts}_h{width}{'' if dt == 1 else '_d' + str(dt)}_n{nh}_t{t}"
 
@@ -200,8 +205,9 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
         if not p.exists() or p.read_text() != src:
             p.write_text(src)
         files.append(p)
-    for nh, t, parts, dt, width in SPLIT_INSTANCES:
-        name = _split_name(nh, t, parts, dt, width)
+    split_units = [(i, False) for i in SPLIT_INSTANCES] + [(i, True) for i in SPLIT_INSTANCES if _has_four_slot_twin(i)]
+    for (nh, t, parts, dt, width), four in split_units:
+        name = _split_name(nh, t, parts, dt, width) + ("_s4" if four else "")
         src = f"""// generated by flowfusion_amd/build.py -- do not edit
 #include <atomic>
 #include "ff_registry.h"
@@ -209,7 +215,7 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
 namespace ff {{
 int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
 {{
-    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}, {width}>;
+    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}, {width}{', 4' if four else ''}>;
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
     hipError_t err = hipGetDevice(&dev);
@@ -262,10 +268,13 @@ int launch_{name}_coop(const KernelArgs* a, unsigned grid, unsigned lds, hipStre
         [f"int launch_{_inst_name(*i)}_coop(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in INSTANCES
          if _has_coop(i[1], i[7])] +
         [f"int launch_{_wide_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in WIDE_INSTANCES] +
-        [f"int launch_{_split_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in SPLIT_INSTANCES]
+        [f"int launch_{_split_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in SPLIT_INSTANCES] +
+        [f"int launch_{_split_name(*i)}_s4(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in SPLIT_INSTANCES
+         if _has_four_slot_twin(i)]
     )
     split_rows = ",\n".join(
-        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, launch_{_split_name(*i)}, "{_split_name(*i)}"}}' for i in SPLIT_INSTANCES
+        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, launch_{_split_name(*i)}, "{_split_name(*i)}", '
+        + (f"launch_{_split_name(*i)}_s4" if _has_four_slot_twin(i) else "nullptr") + "}" for i in SPLIT_INSTANCES
     )
     rows = ",\n".join(
         f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, {i[7]}, launch_{_inst_name(*i)}, "{_inst_name(*i)}", '

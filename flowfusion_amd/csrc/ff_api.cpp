@@ -408,8 +408,11 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     const long long spw = k.tangents == 0 ? 128 : (k.tangents == 1 ? 64 : 8 * (16 / (1 + nt)));
     const long long grid = (a->batch + spw - 1) / spw;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
-    const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden, k.parts, k.dt).total;
-    const int herr = k.launch(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
+    // the caller may say how many stage slots the table uses (ff_ode_args.stage_slots): up to four, the twin that keeps
+    // four slots on chip and shares a CU between two workgroups serves the launch (same arithmetic, same results)
+    const bool four = k.launch4 && a->stage_slots >= 1 && a->stage_slots <= 4 && !getenv("FF_SPLIT_NO_TWIN");
+    const unsigned lds = (unsigned)ff::split::lds_map(plan->width, plan->n_hidden, k.parts, k.dt, four ? 4 : 0).total;
+    const int herr = (four ? k.launch4 : k.launch)(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
     if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
     return FF_OK;
 }

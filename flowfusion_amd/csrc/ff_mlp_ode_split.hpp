@@ -301,15 +301,16 @@ __device__ __forceinline__ void dma_fragment(unsigned lds_byte, const void* g, i
 // NH (hidden layers) is a compile-time parameter: with the layer sequence unrolled the evaluation loop is one
 // straight-line body and the accumulator tiles keep their registers (a run-time layer loop made hipcc shuffle all 256
 // accumulator registers at every control-flow join).
-template <int NH, int TM, int NP = 3, int DT = 1, int HW = 256>
-__global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs args)
+// NSL = stage slots kept in LDS: slots_on_chip(DT), or 4 for the four-slot twins (two workgroups per CU)
+template <int NH, int TM, int NP = 3, int DT = 1, int HW = 256, int NSL = slots_on_chip(DT)>
+__global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ? 2 : 1) void mlp_ode_split_kernel(const KernelArgs args)
 {
     static_assert(HW == 256 || HW == 128, "on-chip width: 256 or 128");
     static_assert(TM >= 0 && TM <= 2, "0: state only, 1: Hutchinson column pairs, 2: exact trace (unit tangents)");
     constexpr bool TANGENTS = TM != 0;
     static_assert(NP == 2 || NP == 3, "two (round-to-nearest) or three (truncation) bf16 parts per operand");
     static_assert(DT == 1 || (DT == 2 && NP == 2), "states of up to 32 dimensions: two-part kernels only (LDS)");
-    constexpr int NSLOT = slots_on_chip(DT);           // stage slots kept in LDS: 7 / 4
+    constexpr int NSLOT = NSL;                         // stage slots kept in LDS: 7 / 4
     constexpr int NR = row_tiles(HW);                  // row tiles of 16 rows: 16 (width 256) / 8
     constexpr int NS = ksteps(HW);                     // k-steps of 32 features: 8 / 4
     constexpr int H = HW;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void mlp_ode_split_kernel(const KernelArgs 
     const int col = lane & 15;                         // column within a column block
     const int lane16 = lane * 16;
     const int D = args.dim, C = args.cond_dim;
-    const LdsMap M = lds_map(H, NH, NP, DT);
+    const LdsMap M = lds_map(H, NH, NP, DT, NSL);
 
     // ---- column roles: this lane serves one column of each of the two column blocks ---------------------------------
     const long long wave = (long long)blockIdx.x * 4 + wv;

@@ -35,6 +35,7 @@ struct SplitKernelEntry {
     int width;      // on-chip layer width: 256 or 128
     LaunchFn launch;
     const char* name;
+    LaunchFn launch4;   // four-slot twin (two workgroups per CU; ff_split_layout.h has_four_slot_twin) or NULL
 };
 extern const SplitKernelEntry g_split_kernels[];
 extern const int g_n_split_kernels;

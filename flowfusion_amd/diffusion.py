@@ -378,7 +378,7 @@ class ScoreModel(nn.Module):
         key = ("score-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode,
                self.no_sigma, self._schedule_key())
         table = net.cached_table(key, x.device, lambda: self._ode_table(t_span, method, options, mode))
-        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
+        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, stage_slots=solvers.resolve_method(method).stages, **affine)
         return y, (lp if mode != MODE_STATE else None)
 
     def _schedule_key(self):
@@ -467,9 +467,9 @@ class ScoreModel(nn.Module):
         def launch(x_in, start, stop, mean_last, buf):
             if rng is not None:
                 return net.integrate(x_in, table(start, stop, mean_last), MODE_STATE, cond=conditional,
-                                     rng=(rng[0] & 0x7FFFFFFFFFFFFFFF, rng[1], start))
+                                     rng=(rng[0] & 0x7FFFFFFFFFFFFFFF, rng[1], start), stage_slots=1)
             return net.integrate(x_in, table(start, stop, mean_last), MODE_STATE, cond=conditional,
-                                 noise=buf[: stop - start])
+                                 noise=buf[: stop - start], stage_slots=1)
 
         def first_nan_mean(x_in, start, stop, buf):
             """A launch over steps [start, stop) reported NaN: the reference would have stopped at the first

@@ -139,7 +139,7 @@ class _FlowBase(nn.Module):
             return y, lp
         key = ("flow-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode)
         table = net.cached_table(key, x.device, lambda: self._table(t_span, method, options, mode))
-        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, **affine)
+        y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, stage_slots=solvers.resolve_method(method).stages, **affine)
         return y, (lp if mode != MODE_STATE else None)
 
     def _fused_sample(self, xT, conditional, method, options, atol, rtol, raw_cond=None):

@@ -163,7 +163,7 @@ class FusedNet:
                   cond: Optional[torch.Tensor] = None, probe: Optional[torch.Tensor] = None,
                   noise: Optional[torch.Tensor] = None,
                   in_shift=None, in_scale=None, out_scale=None, out_shift=None,
-                  rng: Optional[Tuple[int, int, int]] = None):
+                  rng: Optional[Tuple[int, int, int]] = None, stage_slots: int = 0):
         """Run the fused integration.  Returns (y_final [B,D], dlogp [B] or empty, status [1]).
         ``rng = (seed, global index of row 0, noise index of table row 0)`` selects in-kernel noise for
         tables with noise rows (instead of a ``noise`` buffer)."""
@@ -185,7 +185,7 @@ class FusedNet:
         else:
             cond = None
         args = (f32(x), cond, f32(probe), f32(noise), self.wpack(dev, mode), f32(etab),
-                f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift), _native.plan_words(plan), mode)
+                f32(in_shift), f32(in_scale), f32(out_scale), f32(out_shift), _native.plan_words(plan, stage_slots), mode)
         if rng is not None:
             if mode != MODE_STATE or noise is not None:
                 raise ValueError("in-kernel noise applies to state-only integration without a noise buffer")
@@ -222,19 +222,21 @@ class FusedNet:
         the CPU tests (kernel-semantics emulator)."""
         plan = self.plan(mode)
         width = plan.width
-        words = _native.plan_words(plan)
         f32 = lambda t: None if t is None else t.detach().to(device, torch.float32).contiguous()
         cond_d = f32(cond) if self.cond_dim > 0 else None
         probe_d = f32(probe)
-        if launcher is None:
+        own = launcher is None
+        if own:
             wpack = self.wpack(device, mode)
-            launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count: torch.ops.flowfusion_amd.mlp_ode_step(
-                y, cond_d, probe_d, k1, kl1, lp0, wpack, etab.to(device), words, mode, n_aux, first, count)
+            launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count, used=0: torch.ops.flowfusion_amd.mlp_ode_step(
+                y, cond_d, probe_d, k1, kl1, lp0, wpack, etab.to(device), _native.plan_words(plan, used), mode, n_aux, first, count)
         passes = [(0, 0)] if mode != MODE_EXACT else exact_trace_passes(self.dim, plan.tile)
 
         def step(y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux):
             n = int(t_rows.numel())
-            self.require_slots(int(slots.max()) + 1, mode, "this adaptive method")
+            used = int(slots.max()) + 1
+            self.require_slots(used, mode, "this adaptive method")
+            hint = {"used": used} if own else {}
             a, b, c1 = schedule(sign * t_rows)
             rows = torch.zeros(n + 2, 32 + width, dtype=torch.float32)
             rows[:n, 0] = sign * a
@@ -248,7 +250,7 @@ class FusedNet:
             ints[n, 3] = use_y
             aux = aux_lp = None
             for i, (first, count) in enumerate(passes):
-                o, olp = launcher(y, k1, kl1 if i == 0 else None, lp0 if i == 0 else None, rows, n_aux, first, count)
+                o, olp = launcher(y, k1, kl1 if i == 0 else None, lp0 if i == 0 else None, rows, n_aux, first, count, **hint)
                 aux = o if aux is None else aux
                 aux_lp = olp if aux_lp is None else aux_lp + olp
             return aux, (aux_lp if mode != MODE_STATE else None)

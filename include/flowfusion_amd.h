@@ -178,7 +178,10 @@ typedef struct ff_ode_args {
                                 depends on the divergence, so one launch can integrate a whole fixed-grid table and
                                 hand back everything the Hutch++ / XTrace estimators need; they are then evaluated
                                 for all rows at once and combined with the tableau's weights by the caller. */
-    int32_t      reserved0;
+    int32_t      stage_slots; /* optional hint: stage slots the table uses (highest slot index + 1, <= FF_MAX_SLOTS); 0 = unknown.
+                                 Plans whose kernel keeps fewer slots on chip than FF_MAX_SLOTS (FF_PREC_BF16X2 with dim > 16:
+                                 4) require the table to stay within them; for the others a hint <= 4 lets the launcher pick a
+                                 twin that trades unused slots for occupancy.  Results do not depend on the hint. */
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */

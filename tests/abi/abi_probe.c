@@ -23,7 +23,7 @@ int main(void)
     OFF(ff_ode_args, mode); OFF(ff_ode_args, tangent_first); OFF(ff_ode_args, tangent_count); OFF(ff_ode_args, k1_in);
     OFF(ff_ode_args, kl1_in); OFF(ff_ode_args, dlogp_in); OFF(ff_ode_args, aux_out); OFF(ff_ode_args, aux_lp_out);
     OFF(ff_ode_args, n_aux); OFF(ff_ode_args, rng_noise_base); OFF(ff_ode_args, rng_seed);
-    OFF(ff_ode_args, rng_sample_offset); OFF(ff_ode_args, jac_out); OFF(ff_ode_args, jac_all); OFF(ff_ode_args, reserved0);
+    OFF(ff_ode_args, rng_sample_offset); OFF(ff_ode_args, jac_out); OFF(ff_ode_args, jac_all); OFF(ff_ode_args, stage_slots);
     SZ(ff_combine_args);
     OFF(ff_combine_args, x); OFF(ff_combine_args, k); OFF(ff_combine_args, coef); OFF(ff_combine_args, x_coef);
     OFF(ff_combine_args, out); OFF(ff_combine_args, n);

@@ -559,3 +559,31 @@ def test_split_random_shapes_against_oracle(built_library):
             assert _state_err(em, so32.sample_sde(prior, draws, cond, steps=10)) < STATE_TOL, tag + ("em",)
     assert all(any(f"_h{w}" in k for k in kernels) for w in (128, 256)) and any("_d2_" in k for k in kernels), sorted(kernels)
     assert len(kernels) >= 24, sorted(kernels)
+
+
+@pytest.mark.gpu
+def test_four_slot_twin_is_bitwise_the_seven_slot_kernel(built_library, monkeypatch):
+    """128-wide bf16x2 kernels for states of up to 16 dimensions have a twin with four stage slots on chip (two workgroups per
+    CU): the launcher picks it when the caller says the table uses at most four slots (ff_ode_args.stage_slots; the front
+    ends pass the method's stage count).  Same arithmetic in the same order: bitwise equal results, for sampling, the
+    Hutchinson and exact-trace log-density and Euler-Maruyama; FF_SPLIT_NO_TWIN=1 pins the seven-slot kernel."""
+    sm, _, _ = _seeded(9, 3, [128, 100, 128], "VPSDE", True, 71, "bf16x2")
+    assert _native.kernel_name(sm._net().plan(0)) == "mlp_ode_split2_h128_n3_t0"
+    torch.manual_seed(6)
+    z, cond = torch.randn(1000, 9, device=DEV), torch.randn(1000, 3, device=DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 10}
+
+    def run():
+        out = [sm.sample_ode_from_base(z, conditional=cond, method="rk4", options=opts)[0]]
+        sm.hutch = True
+        torch.manual_seed(12)
+        out.append(sm.log_prob(z[:200], conditional=cond[:200], method="heun3", options=opts))
+        sm.hutch = False
+        out.append(sm.log_prob(z[:100], conditional=cond[:100], method="rk4", options=opts))          # exact trace
+        out.append(sm._sample_sde_from(z, None, cond, 12, rng=(99, 0)))
+        return out
+    twin = run()
+    monkeypatch.setenv("FF_SPLIT_NO_TWIN", "1")
+    plain = run()
+    for a, b in zip(twin, plain):
+        assert torch.equal(a, b)
