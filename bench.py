@@ -223,6 +223,23 @@ def extra_configs(device):
                 "dtype": "f32", "note": "below ~3/4 of a chip's worth of tiles the launcher gives each tile to a workgroup "
                 "(rows of a layer split over its 4 wavefronts, LDS exchange per layer); bitwise the same results"})
     del sm, net, x0, xe, zs
+    # --- the reference's notebook shape (BASELINE configs[0] as demo_diffusion.ipynb has it): 2-D VE, 3x128, 50,000 points,
+    # DEFAULT arguments -- adaptive dopri5 for sampling (cell 388), dopri5 + exact trace for log_prob (cell 467)
+    torch.manual_seed(0)
+    nb = ScoreModel(MLP(2, 0, EMB, [128] * 3), VESDE()).eval().to(device)
+    zb = torch.randn(50000, 2, device=device, generator=g)
+    xb = torch.randn(50000, 2, device=device, generator=g) * 0.5
+    entry = {"workload": "BASELINE configs[0] as the notebook runs it: 2-D VE-SDE 3x128, 50,000 points, default arguments "
+                         "(sample_ode_from_base: adaptive dopri5; log_prob: dopri5 + exact trace), wall ms of ONE call", "unit": "ms"}
+    for prec in ("f32", "bf16x2"):
+        nb.precision = prec
+        nb.sample_ode_from_base(zb[:512].contiguous())
+        nb.log_prob(xb[:512].contiguous())
+        entry[f"sample_ms_{prec}"] = 1e3 * min(_timed(lambda: nb.sample_ode_from_base(zb), device)[1] for _ in range(3))
+        entry[f"sample_attempts_{prec}"] = dict(nb.last_solver_stats)
+        entry[f"log_prob_ms_{prec}"] = 1e3 * min(_timed(lambda: nb.log_prob(xb), device)[1] for _ in range(3))
+    out.append(entry)
+    del nb, zb, xb
     # --- config 4: 64-dim flow matching, 5x512, 200 fixed Dormand-Prince steps, 2^22 / 8 GPUs = 2^19 per GPU ------
     torch.manual_seed(0)
     f = Fm.ODEFlow(64, [512] * 5).to(device).eval()
