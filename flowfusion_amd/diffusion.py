@@ -664,11 +664,13 @@ class ScoreModel(nn.Module):
 # ------------------------------------------------------------------------------------------------
 class PopulationModelDiffusion(nn.Module):
     def __init__(self, model=None, sde=None, shift=None, scale=None, method="dopri5", no_sigma=False,
-                 hutchinson=False, options=None):
+                 hutchinson=False, options=None, *, precision="f32"):
+        """Arguments as in the reference (diffusion.py:1466-1530); ``precision`` (keyword only, extension) is handed to the
+        inner ``ScoreModel`` (see there)."""
         super().__init__()
         self.model = model
         self.sde = sde
-        self.score_model = ScoreModel(model=self.model, sde=self.sde, hutchinson=hutchinson, no_sigma=no_sigma)
+        self.score_model = ScoreModel(model=self.model, sde=self.sde, hutchinson=hutchinson, no_sigma=no_sigma, precision=precision)
         n = self.model.n_dimensions
         self.register_buffer("shift", shift if shift is not None else torch.zeros(n, dtype=torch.float32))
         self.register_buffer("scale", scale if scale is not None else torch.ones(n, dtype=torch.float32))
@@ -692,11 +694,11 @@ class PopulationModelDiffusion(nn.Module):
 
 class PopulationModelDiffusionConditional(nn.Module):
     def __init__(self, model=None, sde=None, shift=None, scale=None, conditional_shift=None,
-                 conditional_scale=None, no_sigma=False, method="dopri5", options=None):
+                 conditional_scale=None, no_sigma=False, method="dopri5", options=None, *, precision="f32"):
         super().__init__()
         self.model = model
         self.sde = sde
-        self.score_model = ScoreModel(model=self.model, sde=self.sde, no_sigma=no_sigma)
+        self.score_model = ScoreModel(model=self.model, sde=self.sde, no_sigma=no_sigma, precision=precision)
         n, c = self.model.n_dimensions, self.model.n_conditionals
         self.register_buffer("shift", shift if shift is not None else torch.zeros(n, dtype=torch.float32))
         self.register_buffer("scale", scale if scale is not None else torch.ones(n, dtype=torch.float32))

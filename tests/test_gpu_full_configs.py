@@ -240,6 +240,29 @@ def test_population_wrappers_forward_and_log_prob_against_oracle(conditional, sd
     assert _state_err(out, po32.forward(base, cond)) < ADAPT_TOL
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x2"])
+def test_population_wrappers_under_split_precision(prec):
+    """The wrappers' precision= keyword reaches the inner ScoreModel: forward (fixed grid, affine in the epilogue), the default
+    log_prob (adaptive dopri5 + exact trace, affine in front of the loop) and sample_sde on the split-precision kernels
+    agree with the f32 kernels' results."""
+    from flowfusion_amd import diffusion as Dm, _native
+    torch.manual_seed(191)
+    shift, scale = torch.randn(5), torch.rand(5) + 0.5
+    cshift, cscale = torch.randn(3), torch.rand(3) + 0.5
+    pm = Dm.PopulationModelDiffusionConditional(model=Dm.MLP(5, 3, 8, [96, 128]), sde=Dm.VESDE(), shift=shift, scale=scale,
+                                                conditional_shift=cshift, conditional_scale=cscale, method="rk4",
+                                                options={"step_size": 0.02}, precision=prec).eval().to(DEV)
+    assert pm.score_model.precision == prec
+    base, cond = torch.randn(90, 5, device=DEV), torch.randn(90, 3, device=DEV)
+    out = pm(base, cond)
+    assert _native.kernel_name(pm.score_model._net().plan(0)).startswith("mlp_ode_split")
+    lp = pm.log_prob(out[:30], cond[:30])
+    pm.score_model.precision = "f32"
+    out32 = pm(base, cond)
+    lp32 = pm.log_prob(out[:30], cond[:30])
+    assert _state_err(out, out32.cpu()) < STATE_TOL and _logp_err(lp, lp32.cpu()) < ADAPT_TOL
+
+
 def test_population_wrapper_hutchinson_log_prob_fixed_seed():
     pm, po32, _ = _population(False, "VPSDE", True, True, "dopri5", None, 171)
     torch.manual_seed(8)
