@@ -92,7 +92,7 @@ SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3
 
 def _has_four_slot_twin(inst) -> bool:
     """128-wide two-part kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU)."""
-    return inst[2] == 2 and inst[3] == 1 and inst[4] == 128
+    return inst[2] in (2, 3) and inst[3] == 1 and inst[4] == 128
 
 
 def _split_name(nh, t, parts=3, dt=1, width=256) -> str:

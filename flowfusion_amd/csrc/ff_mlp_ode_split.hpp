@@ -318,6 +318,8 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
     constexpr int GB = granule_bytes(NP, HW);          // 24 KiB (three parts) / 16 KiB (two) at width 256, half that at 128
     constexpr int GG = gaps_per_group(NP);             // MFMAs of a group: 12 / 6
     constexpr int NDMA = dma_count(NP, HW);            // fragments of a granule this wavefront fetches
+    // weight buffers in LDS: 3 (the DMA runs two granules ahead) or, in the three-part four-slot twins, 2 (one granule ahead)
+    constexpr int NBUF = (NSL == 4 && DT == 1 && has_four_slot_twin(NP, DT, HW)) ? weight_buffers(NP, 4) : kBuffers;
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
                      lane16 < H * 4 - 16 ? lane16 : H * 4 - 16);
     };
     fetch_c1(0);
-    for (int g = 0; g < 2; ++g) {                      // granules 0 and 1 into buffers 0 and 1
+    for (int g = 0; g < NBUF - 1; ++g) {               // the first NBUF - 1 granules into their buffers
 #pragma unroll
         for (int f = 0; f < NDMA; ++f) dma_fragment(g * GB + my_frag + f * 1024, wbase + dpos + my_frag + f * 1024, lane16);
         dpos += GB;
@@ -522,8 +524,8 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
             // The stream position is periodic in the evaluation loop, so hipcc would compute all ~300 fragment
             // addresses of an evaluation once, ahead of the loop, and keep them in (spilled) SGPRs: hide the bases.
             asm volatile("" : "+s"(rbuf));
-            unsigned wb = rbuf + 2 * GB;
-            if (wb >= 3 * GB) wb -= 3 * GB;            // granule + 2 -> the buffer read before this one
+            unsigned wb = rbuf + (NBUF - 1) * GB;
+            if (wb >= NBUF * GB) wb -= NBUF * GB;      // granule + NBUF - 1 -> the buffer read before this one
             dsrc = wbase + dpos + my_frag;
             ddst = wb + my_frag;
             asm volatile("" : "+s"(dsrc), "+s"(ddst));
@@ -533,7 +535,8 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
         if constexpr (GQ == GRG - kAhead) {
             // everything but the NDMA DMAs issued in this granule has landed, and this wavefront's reads of the current
             // buffer have returned: after the barrier the next granule is visible to all and the previous buffer is free
-            if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            if constexpr (NBUF == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (one granule ahead: all of it)
+            else if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
             else if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else if constexpr (NDMA == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
             __builtin_amdgcn_s_barrier();
 #endif
             rbuf += GB;
-            if (rbuf >= 3 * GB) rbuf = 0;
+            if (rbuf >= NBUF * GB) rbuf = 0;
             wa_next = lane16 + rbuf;
         }
         sfor<GG>([&](auto ii) {

@@ -54,7 +54,10 @@ FF_HD constexpr int slots_on_chip(int dt) { return dt == 1 ? 7 : 4; }
 // ... and a four-slot twin of the 128-wide two-part kernels for states of up to 16 dimensions: with 48 KiB of slots
 // instead of 72 a workgroup takes under half of a CU's LDS and 256 registers per lane suffice, so TWO workgroups share a
 // CU (two wavefronts per SIMD) and one's activation instructions fill the other's MFMA gaps (+26 %, measured).
-FF_HD constexpr bool has_four_slot_twin(int parts, int dt, int w) { return parts == 2 && dt == 1 && w == 128; }
+// (the three-part twin also drops the third weight buffer -- the DMA then runs one granule ahead instead of two -- to get
+// under half of the LDS)
+FF_HD constexpr bool has_four_slot_twin(int parts, int dt, int w) { return (parts == 2 || parts == 3) && dt == 1 && w == 128; }
+FF_HD constexpr int weight_buffers(int parts, int slots) { return (slots == 4 && parts == 3) ? 2 : kBuffers; }
 FF_HD constexpr int granules_per_eval(int n_hidden, int dt = 1, int w = kWidth)
 {
     return (groups_l1(dt, w) + (n_hidden - 1) * groups_hid(w) + groups_out(dt, w)) / granule_groups(w);
@@ -83,7 +86,7 @@ FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts, int dt = 1, int s
 {
     LdsMap m{};
     m.wbuf = 0;
-    m.slots = kBuffers * granule_bytes(parts, H);
+    m.slots = ((slots == 4 && dt == 1) ? weight_buffers(parts, 4) : kBuffers) * granule_bytes(parts, H);
     m.c1 = m.slots + ((slots > 0 ? slots : slots_on_chip(dt)) + 2) * 2 * dt * 256 * 16;
     m.hbias = m.c1 + 2 * 1024;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
