@@ -129,6 +129,58 @@ def test_two_part_packer_rounds_to_nearest(built_library):
     assert np.array_equal(tail[:128], sm.model.NN[1].bias.detach().numpy()) and np.array_equal(tail[256:256 + 7], sm.model.NN[2].bias.detach().numpy())
 
 
+def test_packer_two_state_tiles_width_128(built_library):
+    """FF_PREC_BF16X2, 20 state dimensions, 3 conditional inputs, hidden widths (100, 128): the 128-wide two-tile layout --
+    granules of 4 groups; layer 1 = two k-steps of 8 row tiles (features 0..31 the state, then 0..15 the conditional
+    inputs); hidden layer k-major over 4 k-steps; output layer two row tiles per k-step; biases behind the stream."""
+    torch.manual_seed(6)
+    sm = D.ScoreModel(D.MLP(20, 3, 8, [100, 128]), D.VPSDE(), no_sigma=True, precision="bf16x2").eval()
+    net = sm._net()
+    plan = net.plan(MODE_STATE)
+    assert (plan.precision, plan.width, plan.dregs, plan.n_hidden) == (2, 128, 16, 2) and net.stage_slots(MODE_STATE) == 4
+    assert _native.kernel_name(plan) == "mlp_ode_split2_h128_d2_n2_t0"
+    assert _native.kernel_name(net.plan(MODE_EXACT)) == "mlp_ode_split2_h128_d2_n2_t2" and net.plan(MODE_EXACT).tile == 16
+    words = net.wpack("cpu", MODE_STATE).numpy().view(np.uint32)
+    NR, NS, H = 8, 4, 128
+    n_groups = 2 * NR + NR * NS + 2 * NS
+    assert n_groups % 4 == 0 and words.size == n_groups * 512 + 1 * H + 32
+    E = 8                                                            # time-embedding columns in front of the state columns
+
+    def group(g):
+        frag = words[g * 512:(g + 1) * 512].reshape(2, 64, 4)
+        halves = np.stack([frag & 0xFFFF, frag >> 16], axis=-1).reshape(2, 64, 8)
+        return (halves.astype(np.uint32) << 16).view(np.float32)    # [part, lane, j]
+
+    def parts(w):
+        hi = torch.tensor(w).bfloat16().float().item()
+        return hi, torch.tensor(w - hi).bfloat16().float().item()
+    W0, W1, W2 = (l.weight.detach().numpy() for l in sm.model.NN)
+    for s1, rt, lane in ((0, 0, 0), (0, 6, 21), (1, 3, 47), (1, 7, 63)):
+        vals = group(s1 * NR + rt)
+        row, q = 16 * rt + (lane & 15), lane >> 4
+        for j in range(8):
+            f = _kidx(0, q, j)
+            col = (E + f if f < 20 else None) if s1 == 0 else (E + 20 + f if f < 3 else None)
+            exp = parts(float(W0[row, col])) if (row < 100 and col is not None) else (0.0, 0.0)
+            assert (vals[0, lane, j], vals[1, lane, j]) == exp, (s1, rt, lane, j)
+    for s_, rt, lane in ((0, 0, 5), (2, 7, 33), (3, 4, 60)):
+        vals = group(2 * NR + s_ * NR + rt)
+        row, q = 16 * rt + (lane & 15), lane >> 4
+        for j in range(8):
+            k = _kidx(s_, q, j)
+            exp = parts(float(W1[row, k])) if k < 100 else (0.0, 0.0)
+            assert (vals[0, lane, j], vals[1, lane, j]) == exp
+    for s_, t, lane in ((0, 0, 3), (1, 1, 2), (3, 1, 20), (2, 0, 50)):
+        vals = group(2 * NR + NR * NS + s_ * 2 + t)
+        row, q = 16 * t + (lane & 15), lane >> 4
+        for j in range(8):
+            exp = parts(float(W2[row, _kidx(s_, q, j)])) if row < 20 else (0.0, 0.0)
+            assert (vals[0, lane, j], vals[1, lane, j]) == exp
+    tail = net.wpack("cpu", MODE_STATE).numpy()[n_groups * 512:]
+    assert np.array_equal(tail[:128], sm.model.NN[1].bias.detach().numpy()) and np.array_equal(tail[128:148], sm.model.NN[2].bias.detach().numpy())
+    assert not tail[148:].any()
+
+
 def test_split_precision_scope_and_errors(built_library):
     mk = lambda **kw: _native.make_plan(kw.get("dim", 16), kw.get("cond", 0), kw.get("hidden", [256] * 4), kw.get("mode", MODE_STATE),
                                         kw.get("act", (_native.ACT_SILU, 0.0, 0.0)), _native.PREC_BF16X3)
