@@ -181,6 +181,17 @@ def extra_configs(device):
     out.append(_record("BASELINE configs[2]: 16-dim VP-SDE 4x256, log_prob, Hutchinson divergence, 100-step RK4, batch 2^20",
                        B, "log-probs/s", wall, name_of(net, 1), kms, 2 * 2.0 * mac_per_eval(DIM, UNITS) * tab.shape[0] * B,
                        {"note": "wall includes the reference's CPU draw of the probe (diffusion.py:701) and its upload"}))
+    # the same Hutchinson call on the opt-in 16-bit-operand kernels
+    sm.precision = "bf16x2"
+    sm.log_prob(x0[:256], method="rk4", options=opts)
+    _, wall_h2, _ = _timed(lambda: sm.log_prob(x0, method="rk4", options=opts), device)
+    net2 = sm._net()
+    _, _, kms_h2 = _timed(lambda: net2.integrate(x0, tab, 1, probe=sm.e, stage_slots=4), device)
+    out.append({"workload": "BASELINE configs[2] on precision='bf16x2' (opt-in): the Hutchinson log_prob above", "value": B / wall_h2,
+                "unit": "log-probs/s", "wall_ms": 1e3 * wall_h2, "kernel": _native.kernel_name(net2.plan(1)), "kernel_ms": kms_h2,
+                "dtype": "bf16x2-split, f32 accumulate", "speedup_vs_f32_entry": out[-1]["wall_ms"] / (1e3 * wall_h2)})
+    sm.precision = "f32"
+    net = sm._net()
     # --- the reference's default divergence: exact trace (D unit tangents), 2^16 ---------------------------------
     sm.hutch = False
     Be = 1 << 16
