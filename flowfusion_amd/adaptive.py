@@ -124,6 +124,17 @@ class Dopri5:
                 raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
         self.n_attempts = 0
         self.n_accepted = 0
+        # the tableau as fp32 tensors, once per solve (an attempt then costs a handful of host tensor ops instead of ~40)
+        S = self.tab.stages
+        self._alpha = _f32(self.tab.alpha)
+        self._alpha_is_one = torch.tensor([a == 1.0 for a in self.tab.alpha])
+        self._beta8 = torch.zeros(S - 1, 8)
+        for i, beta in enumerate(self.tab.beta):
+            self._beta8[i, : len(beta)] = _f32(beta)
+        pad = lambda c: torch.cat([_f32(c), torch.zeros(8 - S)])
+        self._c_sol8, self._c_mid8, self._c_err8 = pad(self.tab.c_sol), pad(self.tab.c_mid), pad(self.tab.c_error)
+        self._last_stage = _onehot(S - 1)
+        self._stage_slots = torch.arange(1, S, dtype=torch.int32)
 
     # -- single launches ----------------------------------------------------------------------
     def _deriv(self, t, y, lp, k1=None, kl1=None, h=None):
@@ -138,19 +149,14 @@ class Dopri5:
 
     def _attempt(self, t0, dt, t1, y, lp, f0, fl0):
         """Stages 2..7 of one step from (t0, y) with step dt; returns y1, lp1, f1, fl1, mids, errors."""
-        tab = self.tab
-        S = tab.stages
         t0f, dtf, t1f = _f32(t0), _f32(dt), _f32(t1)              # time enters the stages in the state dtype
-        ts = torch.stack([t1f if a == 1.0 else t0f + a * dtf for a in tab.alpha])
-        cin = torch.zeros(S - 1, 8)
-        for i, beta in enumerate(tab.beta):
-            cin[i, : len(beta)] = _f32(beta) * dtf
-        tail = torch.zeros(4, 8)
-        tail[0, :S] = dtf * _f32(tab.c_sol)                        # y1    = y + dt * k . c_sol
-        tail[1] = _onehot(S - 1)                                   # f1    = the last stage (FSAL)
-        tail[2, :S] = dtf * _f32(tab.c_mid)                        # y_mid = y + dt * k . c_mid
-        tail[3, :S] = dtf * _f32(tab.c_error)                      # err   = dt * k . c_error
-        aux, aux_lp = self.step(y, f0, lp, fl0, ts, cin, torch.arange(1, S, dtype=torch.int32), tail, 0b0101, 4)
+        ts = torch.where(self._alpha_is_one, t1f, t0f + self._alpha * dtf)     # a stage at alpha = 1 sits at t1 itself
+        cin = self._beta8 * dtf
+        tail = torch.stack([dtf * self._c_sol8,                    # y1    = y + dt * k . c_sol
+                            self._last_stage,                      # f1    = the last stage (FSAL)
+                            dtf * self._c_mid8,                    # y_mid = y + dt * k . c_mid
+                            dtf * self._c_err8])                   # err   = dt * k . c_error
+        aux, aux_lp = self.step(y, f0, lp, fl0, ts, cin, self._stage_slots, tail, 0b0101, 4)
         if self.has_lp:
             return aux, aux_lp
         return aux, None
