@@ -82,6 +82,51 @@ class OdeArgs(ctypes.Structure):
         ("jac_out", ctypes.c_void_p),
         ("jac_all", ctypes.c_int32),
         ("stage_slots", ctypes.c_int32),
+        ("gate", ctypes.c_void_p),
+    ]
+
+
+STATUS_NAN, STATUS_BAD_SLOT = 1, 2          # FF_STATUS_*
+SCHED_FLOW, SCHED_VE, SCHED_VP, SCHED_SUBVP = 0, 1, 2, 3     # FF_SCHED_*
+ADAPT_START, ADAPT_FINISH = 1, 2            # FF_ADAPT_START / FF_ADAPT_FINISH
+ADAPT_ERR_UNDERFLOW, ADAPT_ERR_NONFINITE, ADAPT_ERR_MAXSTEPS = 1, 2, 3
+ADAPT_MAX_PASSES = 8
+MAX_SLOTS, MAX_AUX = 7, 4
+
+
+class AdaptState(ctypes.Structure):       # ff_adapt_state (128 bytes of device memory)
+    _fields_ = [
+        ("t", ctypes.c_double), ("dt", ctypes.c_double), ("t_prev", ctypes.c_double), ("dt_prev", ctypes.c_double),
+        ("t_end", ctypes.c_double), ("h0", ctypes.c_double), ("d0", ctypes.c_double), ("d1", ctypes.c_double),
+        ("active", ctypes.c_int32), ("commit", ctypes.c_int32), ("done", ctypes.c_int32), ("error", ctypes.c_int32),
+        ("n_attempts", ctypes.c_int32), ("n_accepted", ctypes.c_int32), ("n_steps", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32), ("last_ratio", ctypes.c_float), ("reserved1", ctypes.c_float * 7),
+    ]
+
+
+class AdaptConfig(ctypes.Structure):      # ff_adapt_config
+    _fields_ = [
+        ("n_stages", ctypes.c_int32), ("order", ctypes.c_int32),
+        ("alpha", ctypes.c_float * (MAX_SLOTS - 1)), ("beta", (ctypes.c_float * 8) * (MAX_SLOTS - 1)),
+        ("c_sol", ctypes.c_float * 8), ("c_mid", ctypes.c_float * 8), ("c_err", ctypes.c_float * 8),
+        ("rtol", ctypes.c_float), ("atol", ctypes.c_float),
+        ("min_step", ctypes.c_double), ("max_step", ctypes.c_double), ("first_step", ctypes.c_double),
+        ("max_num_steps", ctypes.c_int32), ("sched", ctypes.c_int32), ("no_sigma", ctypes.c_int32), ("sign", ctypes.c_float),
+        ("p", ctypes.c_double * 4),
+        ("emb_w", ctypes.c_void_p), ("n_emb", ctypes.c_int32), ("pi", ctypes.c_float),
+        ("w0t", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("h_real", ctypes.c_int32), ("n_tcols", ctypes.c_int32),
+    ]
+
+
+class AdaptBuffers(ctypes.Structure):     # ff_adapt_buffers
+    _fields_ = [
+        ("y", ctypes.c_void_p), ("f0", ctypes.c_void_p), ("lp", ctypes.c_void_p), ("fl0", ctypes.c_void_p),
+        ("aux", ctypes.c_void_p * MAX_AUX), ("aux_lp", ctypes.c_void_p * MAX_AUX), ("aux_lp_pass", ctypes.c_void_p),
+        ("scratch_x", ctypes.c_void_p), ("scratch_lp", ctypes.c_void_p), ("etab", ctypes.c_void_p),
+        ("out_y", ctypes.c_void_p), ("out_lp", ctypes.c_void_p), ("state", ctypes.c_void_p),
+        ("norm_workspace", ctypes.c_void_p), ("norm_only", ctypes.c_void_p * 2), ("norm_only_n", ctypes.c_int64 * 2),
+        ("n_passes", ctypes.c_int32), ("pass_first", ctypes.c_int32 * ADAPT_MAX_PASSES),
+        ("pass_count", ctypes.c_int32 * ADAPT_MAX_PASSES),
     ]
 
 
@@ -164,6 +209,16 @@ def lib() -> ctypes.CDLL:
                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.ff_stage_combine.restype = ctypes.c_int
     L.ff_stage_combine.argtypes = [ctypes.POINTER(CombineArgs), ctypes.c_void_p]
+    L.ff_mlp_ode_adaptive.restype = ctypes.c_int
+    L.ff_mlp_ode_adaptive.argtypes = [ctypes.POINTER(PlanStruct), ctypes.POINTER(OdeArgs), ctypes.POINTER(AdaptConfig),
+                                      ctypes.POINTER(AdaptBuffers), ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                      ctypes.c_int32, ctypes.c_void_p]
+    L.ff_adapt_host_row.restype = ctypes.c_int
+    L.ff_adapt_host_row.argtypes = [ctypes.POINTER(AdaptConfig), ctypes.c_float, ctypes.POINTER(ctypes.c_float),
+                                    ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
+    L.ff_adapt_host_transition.restype = ctypes.c_int
+    L.ff_adapt_host_transition.argtypes = [ctypes.POINTER(AdaptConfig), ctypes.POINTER(AdaptState), ctypes.c_int32,
+                                           ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
 
@@ -185,10 +240,10 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
         name = "bf16x3" if precision == PREC_BF16X3 else "bf16x2"
         raise NotImplementedError(
             f"precision='{name}' (one of the split-precision options 'bf16x3' / 'bf16x2') has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
-            f"activation={act[0]}: the split-precision family covers SiLU networks of 1-6 hidden layers up to 256 wide, "
-            "dim <= 16 (bf16x2: <= 32 with at most 4 Runge-Kutta stages), cond_dim <= 16, state-only (Euler-Maruyama included) and "
-            "Hutchinson / exact-trace solves, fixed grids and the adaptive "
-            "methods; use precision='f32'")
+            f"activation={act[0]}: the split-precision family covers SiLU networks of 1-4 hidden layers up to 256 wide, "
+            "cond_dim <= 16, dim <= 16 in every mode (state-only, Euler-Maruyama included, Hutchinson and exact-trace solves; "
+            "fixed grids and the adaptive methods) and, bf16x2 only, dim <= 32 for state-only solves with at most 4 "
+            "Runge-Kutta stages; use precision='f32'")
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
@@ -304,17 +359,25 @@ def scaled_rms(terms, atol: float, rtol: float, check: Optional[torch.Tensor] = 
         keep.append((num, sub, s0, s1))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        key = (dev.index, stream)
-        if key not in _norm_ws:
-            nbytes = int(lib().ff_scaled_rms_workspace_bytes())
-            _norm_ws[key] = (torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev),
-                             torch.empty(NORM_TERMS + 1, dtype=torch.float32, device=dev))
-        ws, out = _norm_ws[key]
+        ws, out = norm_workspace(dev, stream)
         rc = lib().ff_scaled_rms(arr, len(terms), float(atol), float(rtol), _chk(check, "check", dev),
                                  0 if check is None else check.numel(), out.data_ptr(), ws.data_ptr(), ctypes.c_void_p(stream))
     if rc != FF_OK:
+        ws[:4].zero_()      # whatever happened to the launch, the arrival counter starts the next one from zero
         raise _err(rc, "ff_scaled_rms")
     return out[: len(terms) + 1].tolist()
+
+
+def norm_workspace(dev, stream: int):
+    """(workspace, out) of the norm reductions for this device and stream: the kernels leave the arrival counter at
+    zero, so sequential launches on one stream share a workspace (ff_scaled_rms, the adaptive controller)."""
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, stream)
+    if key not in _norm_ws:
+        nbytes = int(lib().ff_scaled_rms_workspace_bytes())
+        _norm_ws[key] = (torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=dev),
+                         torch.empty(NORM_TERMS + 1, dtype=torch.float32, device=dev))
+    return _norm_ws[key]
 
 
 _PLAN_WORDS = ctypes.sizeof(PlanStruct) // 4

@@ -233,6 +233,12 @@ class Dopri5:
         factor = min(IFACTOR, max(SAFETY / error_ratio ** (1.0 / self.tab.order), dfactor))
         return last_step * factor
 
+    def _fail(self, message: str) -> RuntimeError:
+        """torchdiffeq's assertion as an exception that also says how far the solve got (``.solver_stats``)."""
+        err = RuntimeError(message)
+        err.solver_stats = {"attempts": self.n_attempts, "accepted": self.n_accepted}
+        return err
+
     # -- driver ----------------------------------------------------------------------------------
     def integrate(self, t0: float, t_end: float, y: torch.Tensor, lp: Optional[torch.Tensor]):
         """Advance (y, lp) from solver time t0 to t_end > t0; returns the dense-output values there."""
@@ -244,12 +250,12 @@ class Dopri5:
         n_steps = 0
         while t_end > t_hi:
             if n_steps >= self.max_num_steps:
-                raise RuntimeError(f"max_num_steps exceeded ({n_steps}>={self.max_num_steps})")
+                raise self._fail(f"max_num_steps exceeded ({n_steps}>={self.max_num_steps})")
             if dt == dt:
                 dt = min(max(dt, self.min_step), self.max_step)      # every attempt starts from a clamped step
             ta, tb = t_hi, t_hi + dt
             if not (ta + dt > ta):      # also catches dt = NaN after a non-finite error estimate
-                raise RuntimeError(f"underflow in dt {dt}")
+                raise self._fail(f"underflow in dt {dt}")
             aux, aux_lp = self._attempt(ta, dt, tb, y, lp, f0, fl0)
             self.n_attempts += 1
             y1, f1, ymid, yerr = aux[0], aux[1], aux[2], aux[3]
@@ -267,7 +273,7 @@ class Dopri5:
                 accept = True
             if accept:
                 if y1_bad:
-                    raise RuntimeError("non-finite values in state `y`")
+                    raise self._fail("non-finite values in state `y`")
                 self.n_accepted += 1
                 interp = (ta, tb, dt, y, y1, ymid, f0, f1,
                           (lp, lp1, lpmid, fl0, fl1) if self.has_lp else None)

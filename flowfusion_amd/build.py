@@ -30,8 +30,15 @@ ARCH = "gfx950"
 #   H        hidden width on chip;  DREGS / CREGS state / conditional registers per lane
 #            (TILE 32: dim <= 2*DREGS; TILE 16: dim <= 4*DREGS)
 #   TANGENTS divergence-capable;  WPS waves per SIMD (launch bound);  RING weight chunks in flight
-#   ACT      FF_ACT_* code of the hidden activation compiled in: 0 = SiLU (the reference default), 1..8 the others,
-#            9 = any non-SiLU activation, chosen at run time
+#   ACT      FF_ACT_* code of the hidden activation compiled in: 0 = SiLU (the reference default and the only activation
+#            its code, docs and notebooks ever use), 1..8 the others, 9 = any non-SiLU activation, chosen at run time
+#
+# Round 3: the clean build was cut from 265 translation units / 68 CPU-minutes to what a BASELINE configuration, a
+# reference demo shape or a documented option of the reference's constructors reaches.
+# FF_BUILD_FULL=1 restores the round-2 set (compiled-in activations, 5-6 hidden layers on the split family, ...) for
+# A/B measurements.
+FULL = os.environ.get("FF_BUILD_FULL", "") not in ("", "0")
+
 INSTANCES = [
     # narrow networks: 32 samples per wavefront, one wavefront per SIMD
     (32, h, d, c, t, 1, 8, 0)
@@ -40,14 +47,15 @@ INSTANCES = [
     for c in (0, 8)
     for t in (0, 1)
 ] + [
-    # width 256 on the 32-wide tile: kept for A/B runs against the two-wave kernels (FF_TILE=32)
-    (32, 256, 8, 0, t, 1, 8, 0) for t in (0, 1)
-] + [
     # Two wavefronts per SIMD: with 16 samples per wavefront a 256-wide network needs only 64 + 64
     # activation/accumulator registers, so two wavefronts share a SIMD and one's VALU work (SiLU,
     # stage bookkeeping) overlaps the other's MFMAs -- a single wavefront cannot overlap its own
     # VALU with f32 MFMAs (measured: scratch/bench_proto3.hip).
     (16, 256, d, c, t, 2, 8, 0) for (d, c) in ((4, 0), (4, 4), (8, 4)) for t in (0, 1)
+] + [
+    # up to 32 conditional inputs (and 32 dimensions) at width 256 -- in round 2 a 512-wide instance caught these at 4x
+    # the matrix work and two minutes of compile time
+    (16, 256, 8, 8, t, 2, 8, 0) for t in (0, 1)
 ] + [
     # up to 64 dimensions on a 256-wide network (one wavefront per SIMD: the stage slots of 64 dimensions take
     # 114 KB of LDS per workgroup) -- otherwise such a model would run on the 512-wide kernels at 4x the FLOPs
@@ -57,41 +65,52 @@ INSTANCES = [
     # samples fill the register file of one wavefront per SIMD
     (16, 512, 16, 4, t, 1, 4, 0) for t in (0, 1)
 ] + [
-    # catch-all for models with up to 32 conditional inputs (any width <= 512, any dimension <= 64)
-    (16, 512, 16, 8, t, 1, 4, 0) for t in (0, 1)
+    # non-default activations (`activation=` of the reference constructors): ONE instantiation per width and mode that
+    # chooses the function at run time (ACT = 9; the chosen kind's stages run back to back behind a wave-uniform switch).
+    # The divergence-capable 256-wide one runs one wavefront per SIMD: with the switch at every activation site two
+    # wavefronts per SIMD spill 187 registers.
+    (32, 128, 16, 8, 0, 1, 8, 9), (32, 128, 16, 8, 1, 1, 8, 9),
+    (16, 256, 8, 4, 0, 2, 8, 9), (16, 256, 8, 4, 1, 1, 8, 9),
+    (16, 512, 16, 4, 0, 1, 4, 9), (16, 512, 16, 4, 1, 1, 4, 9),
+] + ([
+    # round-2 extras (FF_BUILD_FULL): width 256 on the 32-wide tile (A/B runs, FF_TILE=32); up to 32 conditional inputs
+    # at width 512 (the wide catch-alls serve them otherwise); every non-SiLU activation compiled in per width <= 256
+    (32, 256, 8, 0, 0, 1, 8, 0), (32, 256, 8, 0, 1, 1, 8, 0),
+    (16, 512, 16, 8, 0, 1, 4, 0), (16, 512, 16, 8, 1, 1, 4, 0),
 ] + [
-    # non-default activations (`activation=` of the reference constructors; ACT = FF_ACT_* code 1..8, compiled in and
-    # staged like SiLU): one covering shape per width <= 256 and activation
     (tile, h, d, c, t, wps, ring, act)
     for act in range(1, 9)
     for (tile, h, d, c, wps, ring) in ((32, 64, 16, 8, 1, 8), (32, 128, 16, 8, 1, 8), (16, 256, 8, 4, 2, 8))
     for t in (0, 1)
-] + [
-    # ... and at width 512, where one kernel takes two minutes to compile, ONE instantiation per mode that chooses the
-    # activation at run time (ACT = 9)
-    (16, 512, 16, 4, t, 1, 4, 9) for t in (0, 1)
-]
+] if FULL else [])
 
 # Wide catch-alls (kernel template WIDE: cooperative at every batch size, hidden operands read from LDS): networks up
 # to 1024 wide, states up to 128 dimensions, up to 64 conditional inputs.  (TILE, H, DREGS, CREGS, TANGENTS)
-WIDE_INSTANCES = [(16, 1024, d, c, t) for (d, c) in ((16, 8), (32, 16)) for t in (0, 1)]
+WIDE_INSTANCES = [(16, 1024, d, c, t) for (d, c) in (((16, 8), (32, 16)) if FULL else ((32, 16),)) for t in (0, 1)]
 
 
 def _wide_name(tile, h, d, c, t) -> str:
     return f"mlp_ode_m{tile}_h{h}_d{d}_c{c}_t{t}_wide"
 
 
-# split-precision family (width 256): (hidden layers, TANGENTS, bf16 parts per operand: 3 = FF_PREC_BF16X3, 2 = FF_PREC_BF16X2)
-# ... and 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32, two-part kernels only)
-# TANGENTS here: 0 state only, 1 Hutchinson column pairs, 2 exact trace (value column + unit tangents)
-# ... and the on-chip width: 256, or 128 for networks up to 128 wide (1-4 hidden layers: the reference's demo sizes)
-SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
-                  [(nh, t, 2, 2, 256) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
-                  [(nh, t, parts, dt, 128) for (parts, dt) in ((3, 1), (2, 1), (2, 2)) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
+# split-precision family (opt-in `precision=`): (hidden layers, TANGENTS, bf16 parts per operand: 3 = FF_PREC_BF16X3,
+# 2 = FF_PREC_BF16X2, 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32 (two-part kernels only), on-chip
+# width: 256, or 128 for networks up to 128 wide).  TANGENTS: 0 state only, 1 Hutchinson column pairs, 2 exact trace.
+# Frozen in round 3 at what the BASELINE configurations and the reference's demo networks reach: 1-4 hidden layers
+# (configs 2, 3 and 5 are 4x256, the notebooks 3x128), every mode for states of up to 16 dimensions, state-only
+# (Euler-Maruyama: config 5) for 17-32 dimensions, 128-wide instances for the two-part option only.
+if FULL:
+    SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
+                      [(nh, t, 2, 2, 256) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
+                      [(nh, t, parts, dt, 128) for (parts, dt) in ((3, 1), (2, 1), (2, 2)) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
+else:
+    SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4) for t in (0, 1, 2)] + \
+                      [(nh, 0, 2, 2, 256) for nh in (1, 2, 3, 4)] + \
+                      [(nh, t, 2, 1, 128) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 
 
 def _has_four_slot_twin(inst) -> bool:
-    """128-wide two-part kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU)."""
+    """128-wide kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU)."""
     return inst[2] in (2, 3) and inst[3] == 1 and inst[4] == 128
 
 
@@ -113,22 +132,20 @@ def _hipcc() -> str:
 
 
 def _inst_name(tile, h, d, c, t, wps, ring, act) -> str:
-    return f"mlp_ode_m{tile}_h{h}_d{d}_c{c}_t{t}" + (f"_w{wps}" if wps != 1 else "") + (f"_a{act}" if act else "")
+    # (the name carries _w<n> only where it always has -- the two-waves-per-SIMD SiLU kernels)
+    return f"mlp_ode_m{tile}_h{h}_d{d}_c{c}_t{t}" + (f"_w{wps}" if (wps != 1 and act == 0) else "") + (f"_a{act}" if act else "")
 
 
-def _gen_sources() -> list[Path]:
-    GEN.mkdir(parents=True, exist_ok=True)
-    files = []
-    for tile, h, d, c, t, wps, ring, act in INSTANCES:
-        name = _inst_name(tile, h, d, c, t, wps, ring, act)
-        src = f"""// generated by flowfusion_amd/build.py -- do not edit
+def _launcher_unit(name: str, header: str, kernel_expr: str) -> str:
+    """One translation unit: the instantiation `kernel_expr` behind `int launch_<name>(args, grid, lds, stream)`."""
+    return f"""// generated by flowfusion_amd/build.py -- do not edit
 #include <atomic>
 #include "ff_registry.h"
-#include "ff_mlp_ode.hpp"
+#include "{header}"
 namespace ff {{
 int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
 {{
-    auto kern = mlp_ode_kernel<{tile}, {h}, {d}, {c}, {'true' if t else 'false'}, {wps}, {ring}, {act}>;
+    auto kern = {kernel_expr};
     // the dynamic-LDS limit is a per-device attribute of the function: set it once per device of this process
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
@@ -144,125 +161,36 @@ int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t 
 }}
 }}
 """
-        p = GEN / f"{name}.hip"
-        if not p.exists() or p.read_text() != src:
-            p.write_text(src)
-        files.append(p)
+
+
+def _write(path: Path, text: str) -> Path:
+    if not path.exists() or path.read_text() != text:
+        path.write_text(text)
+    return path
+
+
+def _gen_sources() -> list[Path]:
+    GEN.mkdir(parents=True, exist_ok=True)
+    files = []
+    tf = lambda t: "true" if t else "false"
+    for tile, h, d, c, t, wps, ring, act in INSTANCES:
+        name = _inst_name(tile, h, d, c, t, wps, ring, act)
+        files.append(_write(GEN / f"{name}.hip", _launcher_unit(
+            name, "ff_mlp_ode.hpp", f"mlp_ode_kernel<{tile}, {h}, {d}, {c}, {tf(t)}, {wps}, {ring}, {act}>")))
         if _has_coop(h, act):
             # cooperative twin (small batches): same layout, one tile per workgroup; a translation unit of its own
             cwps = 2 if h <= 256 else 1
-            csrc = f"""// generated by flowfusion_amd/build.py -- do not edit
-#include <atomic>
-#include "ff_registry.h"
-#include "ff_mlp_ode.hpp"
-namespace ff {{
-int launch_{name}_coop(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
-{{
-    auto kern = mlp_ode_kernel<{tile}, {h}, {d}, {c}, {'true' if t else 'false'}, {cwps}, 4, {act}, true>;
-    static std::atomic<unsigned char> ready[kMaxDevices];
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return (int)err;
-    if (dev < 0 || dev >= kMaxDevices || !ready[dev].load(std::memory_order_acquire)) {{
-        err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return (int)err;
-        if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
-    }}
-    void* params[] = {{(void*)a}};
-    return (int)hipLaunchKernel((const void*)kern, dim3(grid), dim3(256), params, lds, s);
-}}
-}}
-"""
-            p = GEN / f"{name}_coop.hip"
-            if not p.exists() or p.read_text() != csrc:
-                p.write_text(csrc)
-            files.append(p)
+            files.append(_write(GEN / f"{name}_coop.hip", _launcher_unit(
+                f"{name}_coop", "ff_mlp_ode.hpp", f"mlp_ode_kernel<{tile}, {h}, {d}, {c}, {tf(t)}, {cwps}, 4, {act}, true>")))
     for tile, h, d, c, t in WIDE_INSTANCES:
         name = _wide_name(tile, h, d, c, t)
-        src = f"""// generated by flowfusion_amd/build.py -- do not edit
-#include <atomic>
-#include "ff_registry.h"
-#include "ff_mlp_ode.hpp"
-namespace ff {{
-int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
-{{
-    auto kern = mlp_ode_kernel<{tile}, {h}, {d}, {c}, {'true' if t else 'false'}, 1, 4, 0, true, true>;
-    static std::atomic<unsigned char> ready[kMaxDevices];
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return (int)err;
-    if (dev < 0 || dev >= kMaxDevices || !ready[dev].load(std::memory_order_acquire)) {{
-        err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return (int)err;
-        if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
-    }}
-    void* params[] = {{(void*)a}};
-    return (int)hipLaunchKernel((const void*)kern, dim3(grid), dim3(256), params, lds, s);
-}}
-}}
-"""
-        p = GEN / f"{name}.hip"
-        if not p.exists() or p.read_text() != src:
-            p.write_text(src)
-        files.append(p)
+        files.append(_write(GEN / f"{name}.hip", _launcher_unit(
+            name, "ff_mlp_ode.hpp", f"mlp_ode_kernel<{tile}, {h}, {d}, {c}, {tf(t)}, 1, 4, 0, true, true>")))
     split_units = [(i, False) for i in SPLIT_INSTANCES] + [(i, True) for i in SPLIT_INSTANCES if _has_four_slot_twin(i)]
     for (nh, t, parts, dt, width), four in split_units:
         name = _split_name(nh, t, parts, dt, width) + ("_s4" if four else "")
-        src = f"""// generated by flowfusion_amd/build.py -- do not edit
-#include <atomic>
-#include "ff_registry.h"
-#include "ff_mlp_ode_split.hpp"
-namespace ff {{
-int launch_{name}(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
-{{
-    auto kern = split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}, {width}{', 4' if four else ''}>;
-    static std::atomic<unsigned char> ready[kMaxDevices];
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return (int)err;
-    if (dev < 0 || dev >= kMaxDevices || !ready[dev].load(std::memory_order_acquire)) {{
-        err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return (int)err;
-        if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
-    }}
-    void* params[] = {{(void*)a}};
-    return (int)hipLaunchKernel((const void*)kern, dim3(grid), dim3(256), params, lds, s);
-}}
-}}
-"""
-        p = GEN / f"{name}.hip"
-        if not p.exists() or p.read_text() != src:
-            p.write_text(src)
-        files.append(p)
-        if _has_coop(h, act):
-            # cooperative twin (small batches): same layout, one tile per workgroup; a translation unit of its own
-            cwps = 2 if h <= 256 else 1
-            csrc = f"""// generated by flowfusion_amd/build.py -- do not edit
-#include <atomic>
-#include "ff_registry.h"
-#include "ff_mlp_ode.hpp"
-namespace ff {{
-int launch_{name}_coop(const KernelArgs* a, unsigned grid, unsigned lds, hipStream_t s)
-{{
-    auto kern = mlp_ode_kernel<{tile}, {h}, {d}, {c}, {'true' if t else 'false'}, {cwps}, 4, {act}, true>;
-    static std::atomic<unsigned char> ready[kMaxDevices];
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err != hipSuccess) return (int)err;
-    if (dev < 0 || dev >= kMaxDevices || !ready[dev].load(std::memory_order_acquire)) {{
-        err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return (int)err;
-        if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
-    }}
-    void* params[] = {{(void*)a}};
-    return (int)hipLaunchKernel((const void*)kern, dim3(grid), dim3(256), params, lds, s);
-}}
-}}
-"""
-            p = GEN / f"{name}_coop.hip"
-            if not p.exists() or p.read_text() != csrc:
-                p.write_text(csrc)
-            files.append(p)
+        files.append(_write(GEN / f"{name}.hip", _launcher_unit(
+            name, "ff_mlp_ode_split.hpp", f"split::mlp_ode_split_kernel<{nh}, {t}, {parts}, {dt}, {width}{', 4' if four else ''}>")))
     decls = "\n".join(
         [f"int launch_{_inst_name(*i)}(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in INSTANCES] +
         [f"int launch_{_inst_name(*i)}_coop(const KernelArgs*, unsigned, unsigned, hipStream_t);" for i in INSTANCES
@@ -300,13 +228,30 @@ const SplitKernelEntry g_split_kernels[] = {{
 const int g_n_split_kernels = {len(SPLIT_INSTANCES)};
 }}
 """
-    p = GEN / "ff_table.cpp"
-    if not p.exists() or p.read_text() != table:
-        p.write_text(table)
-    files.append(p)
+    files.append(_write(GEN / "ff_table.cpp", table))
     files.append(CSRC / "ff_api.cpp")
     files.append(CSRC / "ff_aux.hip")
+    files.append(CSRC / "ff_adaptive.hip")
     return files
+
+
+def _cost(src: Path) -> float:
+    """Rough compile seconds of a translation unit (measured in round 3, /tmp timing of a clean build): the pool starts
+    the longest first so that none of them trails the others."""
+    import re
+    n = src.name
+    m = re.match(r"mlp_ode_split(\d?)_h(\d+)(_d2)?_n(\d)_t(\d)", n)
+    if m:
+        parts, h, d2, nh, t = m.group(1) or "3", int(m.group(2)), bool(m.group(3)), int(m.group(4)), int(m.group(5))
+        base = (4.5 if parts == "3" else 3.2) * (2.2 if t else 1.0) * (1.4 if d2 else 1.0) * (1.0 if h == 256 else 0.3)
+        return base * (1 + nh)
+    if "_h1024_" in n:
+        return 95 if "_t1" in n else 55
+    if "_h512_" in n:
+        return 12 if "_coop" in n else (90 if "_t1" in n else 58)
+    if "_h256_" in n:
+        return 5 if "_coop" in n else 16
+    return 6
 
 
 _INCLUDE_RE = None
@@ -365,8 +310,8 @@ def build(verbose: bool = False, jobs: int | None = None) -> Path:
     LIBDIR.mkdir(parents=True, exist_ok=True)
     srcs = _gen_sources()
     jobs = jobs or min(8, os.cpu_count() or 1)
-    # the slowest translation units (512- and 1024-wide kernels: two minutes each) first, so they do not trail the pool
-    order = sorted(srcs, key=lambda s: (0 if ("_h512_" in s.name or "_h1024_" in s.name) else 1, s.name))
+    # longest first (estimated), so that no slow translation unit trails the pool
+    order = sorted(srcs, key=lambda s: (-_cost(s), s.name))
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         done = dict(zip(order, ex.map(lambda s: _compile(s, _deps_hash(s), verbose), order)))
     objs = [done[s] for s in srcs]

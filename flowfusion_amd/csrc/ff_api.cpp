@@ -7,14 +7,17 @@
 #include "ff_layout.h"
 #include "ff_split_layout.h"
 #include "ff_registry.h"
+#include "ff_adapt_logic.h"
 
 static_assert(FF_MAX_SLOTS == ff::kSlots, "slot count mismatch between header and kernel");
 static_assert(FF_MAX_AUX == ff::kAux, "aux count mismatch between header and kernel");
 static_assert(FF_ROW_HDR * 4 == sizeof(ff::RowHdr), "row header mismatch");
+static_assert(FF_STATUS_NAN == ff::kStatusNaN && FF_STATUS_BAD_SLOT == ff::kStatusBadSlot, "status bits mismatch");
+static_assert(sizeof(ff_adapt_state) == 128, "controller state is 128 bytes");
 
 static thread_local int t_last_hip_error = 0;
 
-extern "C" const char* ff_version(void) { return "flowfusion_amd 0.2 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 / bf16x2 split on 16x16x32 bf16; in-register layer chaining)"; }
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.3 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 / bf16x2 split on 16x16x32 bf16; in-register layer chaining; device-side adaptive step control)"; }
 
 extern "C" int ff_kernel_count(void) { return ff::g_n_kernels + ff::g_n_split_kernels; }
 
@@ -389,9 +392,14 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     if (a->jac_out || (a->noise && k.tangents)) return FF_ERR_UNSUPPORTED;
     if (a->noise && a->noise_stride < a->batch * (int64_t)plan->dim) return FF_ERR_BADARG;
     if (a->n_aux < 0 || a->n_aux > FF_MAX_AUX) return FF_ERR_BADARG;
+    // stage slots: the table's promise must fit what the kernel keeps on chip (a row naming a slot beyond it would
+    // land on the parked stage input and the state: the kernel refuses such a row, FF_STATUS_BAD_SLOT)
+    if (a->stage_slots < 0 || a->stage_slots > FF_MAX_SLOTS) return FF_ERR_BADARG;
+    if (a->stage_slots > ff::split::slots_on_chip(k.dt)) return FF_ERR_UNSUPPORTED;
     if (a->batch == 0) return FF_OK;
     ff::KernelArgs ka;
     memset(&ka, 0, sizeof(ka));
+    ka.gate = a->gate;
     ka.x_in = a->x_in; ka.x_out = a->x_out; ka.cond = a->cond; ka.probe = a->probe;
     ka.dlogp_out = a->dlogp_out; ka.wpack = a->wpack; ka.etab = a->etab;
     ka.in_shift = a->in_shift; ka.in_scale = a->in_scale; ka.out_scale = a->out_scale; ka.out_shift = a->out_shift;
@@ -437,6 +445,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if ((a->mode != FF_MODE_STATE) != (k.tangents != 0)) return FF_ERR_BADARG;
     if (a->mode == FF_MODE_HUTCH && !a->probe) return FF_ERR_BADARG;
     if (a->mode != FF_MODE_STATE && !a->dlogp_out) return FF_ERR_BADARG;
+    if (a->stage_slots < 0 || a->stage_slots > FF_MAX_SLOTS) return FF_ERR_BADARG;
     if (a->batch == 0) return FF_OK;
 
     ff::KernelArgs ka;
@@ -455,6 +464,7 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     ka.jac_out = a->jac_out;
     ka.jac_all = a->jac_out && a->jac_all ? 1 : 0;
     ka.act_kind = plan->activation; ka.act_p0 = plan->act_param[0]; ka.act_p1 = plan->act_param[1];
+    ka.gate = a->gate;
     ka.etab_stride = FF_ROW_HDR + plan->width;
     const ff::Layout L = plan_layout(plan);
     if (L.total_floats * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
@@ -480,4 +490,36 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     const int herr = (coop ? k.launch_coop : k.launch)(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
     if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
     return FF_OK;
+}
+
+// ---- the device-side adaptive controller's arithmetic, on the host (tests without a GPU; ff_adapt_logic.h) ------------
+extern "C" int ff_adapt_host_row(const ff_adapt_config* c, float t_real, float* a_out, float* b_out, float* c1_out)
+{
+    if (!c || !a_out || !b_out || !c1_out || !c->w0t || !c->b0 || c->h_real < 1 || c->n_tcols < 1 || c->n_tcols > 64) return FF_ERR_BADARG;
+    if (c->sched != FF_SCHED_FLOW && (!c->emb_w || c->n_tcols != 2 * c->n_emb)) return FF_ERR_BADARG;
+    float a, b, feat[64];
+    ff::adapt::schedule_ab(*c, t_real, &a, &b);
+    *a_out = c->sign * a;
+    *b_out = c->sign * b;
+    for (int k = 0; k < c->n_tcols; ++k) feat[k] = ff::adapt::time_feature(*c, t_real, k);
+    for (int h = 0; h < c->h_real; ++h) c1_out[h] = ff::adapt::c1_from_features(*c, feat, h);
+    return FF_OK;
+}
+
+extern "C" int ff_adapt_host_transition(const ff_adapt_config* c, ff_adapt_state* s, int32_t phase, const float* norms)
+{
+    if (!c || !s || (phase != ff::adapt::kPhaseFirst && !norms)) return FF_ERR_BADARG;
+    switch (phase) {
+    case ff::adapt::kPhaseInit1:
+        s->d0 = (double)norms[0];
+        return ff::adapt::transition(*c, *s, phase, norms + 1, 1) == ff::adapt::kRowsDerivAtH0 ? 1 : 0;
+    case ff::adapt::kPhaseInit2:
+        return ff::adapt::transition(*c, *s, phase, norms, 1) == ff::adapt::kRowsAttempt ? 1 : 0;
+    case ff::adapt::kPhaseStep:
+        return ff::adapt::transition(*c, *s, phase, norms, 2) == ff::adapt::kRowsAttempt ? 1 : 0;
+    case ff::adapt::kPhaseFirst:
+        return ff::adapt::transition(*c, *s, phase, norms, 0) == ff::adapt::kRowsAttempt ? 1 : 0;
+    default:
+        return FF_ERR_BADARG;
+    }
 }

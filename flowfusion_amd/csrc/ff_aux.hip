@@ -21,10 +21,9 @@
 #include <stdint.h>
 #include "flowfusion_amd.h"
 #include "ff_philox.h"
+#include "ff_norm.h"
 
 namespace ff {
-
-typedef float f32x4a __attribute__((ext_vector_type(4)));
 
 // one thread per (row, block of 4 dimensions): counter = (global row lo/hi, noise index, dim / 4)
 __global__ __launch_bounds__(256) void normal_fill_kernel(float* __restrict__ out, long long batch, int dim, int nblk,
@@ -83,113 +82,12 @@ __global__ __launch_bounds__(256) void stage_combine_kernel(const CombineArgs a)
     }
 }
 
-// ---- scaled RMS norms of an adaptive step (one launch, one small read-back) ----------------------------------------
-// out[i] = sqrt(mean_k (((num_i[k] - sub_i[k]) / (atol + rtol * max(|s0_i[k]|, |s1_i[k]|)))^2)),  out[n_terms] = 1 if
-// `check` holds a non-finite value else 0.  Deterministic: every block reduces its grid-stride share in a fixed tree,
-// writes one partial per term to the workspace, and the block that arrives last adds the partials up in a fixed order
-// (double accumulation) -- no floating-point atomics, so equal inputs give equal norms and the accept / reject
-// decisions of two runs agree.  Workspace: 1 counter word (left at zero) + kNormBlocks x (FF_NORM_TERMS + 1) doubles.
-constexpr int kNormBlocks = 2048;      // 8 workgroups per CU: enough 16-byte loads in flight to stream at the HBM rate
-
-struct NormArgs {
-    const float* num[FF_NORM_TERMS];
-    const float* sub[FF_NORM_TERMS];
-    const float* s0[FF_NORM_TERMS];
-    const float* s1[FF_NORM_TERMS];
-    long long n[FF_NORM_TERMS];
-    int vec_ok[FF_NORM_TERMS];   // every array of the term 16-byte aligned: the body runs on float4
-    const float* check;
-    long long n_check;
-    int check_vec_ok;
-    int n_terms;
-    float atol, rtol;
-    float* out;
-    unsigned* counter;
-    double* partial;       // [kNormBlocks][FF_NORM_TERMS + 1]
-};
-
-__device__ __forceinline__ double block_sum(double v, double* sh)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
-    }
-    return t;              // valid on thread 0
-}
-
-__device__ __forceinline__ double scaled_sq(float num, float sub, float s0, float s1, float atol, float rtol)
-{
-    const float q = (num - sub) / (atol + rtol * fmaxf(fabsf(s0), fabsf(s1)));
-    return (double)q * (double)q;
-}
-
 __global__ __launch_bounds__(256) void scaled_rms_kernel(const NormArgs a)
 {
     __shared__ double sh[4];
     __shared__ bool last;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const f32x4a zero4 = f32x4a{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < a.n_terms; ++t) {
-        double acc = 0.0;
-        const float* num = a.num[t]; const float* sub = a.sub[t]; const float* s0 = a.s0[t]; const float* s1 = a.s1[t];
-        const long long n4 = a.vec_ok[t] ? a.n[t] / 4 : 0;
-        for (long long i = tid; i < n4; i += stride) {
-            const f32x4a vn = ((const f32x4a*)num)[i];
-            const f32x4a vs = sub ? ((const f32x4a*)sub)[i] : zero4;
-            const f32x4a v0 = ((const f32x4a*)s0)[i];
-            const f32x4a v1 = s1 ? ((const f32x4a*)s1)[i] : zero4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc += scaled_sq(vn[j], vs[j], v0[j], v1[j], a.atol, a.rtol);
-        }
-        for (long long i = 4 * n4 + tid; i < a.n[t]; i += stride)      // unaligned input or the last n % 4 elements
-            acc += scaled_sq(num[i], sub ? sub[i] : 0.f, s0[i], s1 ? s1[i] : 0.f, a.atol, a.rtol);
-        const double tot = block_sum(acc, sh);
-        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
-    }
-    {
-        double bad = 0.0;
-        const long long n4 = a.check_vec_ok ? a.n_check / 4 : 0;
-        for (long long i = tid; i < n4; i += stride) {
-            const f32x4a v = ((const f32x4a*)a.check)[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bad += (v[j] - v[j] == 0.f) ? 0.0 : 1.0;        // NaN or infinity
-        }
-        for (long long i = 4 * n4 + tid; i < a.n_check; i += stride) {
-            const float v = a.check[i];
-            bad += (v - v == 0.f) ? 0.0 : 1.0;
-        }
-        const double tot = block_sum(bad, sh);
-        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last) {
-        // the block that arrives last adds the partials up: thread i takes blocks i, i + 256, ... in that order, then the
-        // same fixed tree as above -- the grid size depends on the array sizes only, so equal inputs give equal sums
-        __threadfence();
-        for (int t = 0; t <= a.n_terms; ++t) {
-            const int col = t < a.n_terms ? t : FF_NORM_TERMS;
-            double acc = 0.0;
-            for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
-                acc += __builtin_nontemporal_load(&a.partial[(size_t)b * (FF_NORM_TERMS + 1) + col]);
-            const double tot = block_sum(acc, sh);
-            if (threadIdx.x == 0) {
-                if (t < a.n_terms) a.out[t] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
-                else a.out[a.n_terms] = tot > 0.0 ? 1.f : 0.f;
-            }
-        }
-        if (threadIdx.x == 0) *a.counter = 0u;          // ready for the next launch on this stream
-    }
+    __shared__ float res[FF_NORM_TERMS + 1];
+    scaled_rms_reduce(a, sh, &last, res);
 }
 
 static unsigned stream_grid(long long work_items)
@@ -224,22 +122,8 @@ extern "C" int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float a
     if (!terms || n_terms < 1 || n_terms > FF_NORM_TERMS || !out || !workspace || n_check < 0 || (n_check > 0 && !check))
         return FF_ERR_BADARG;
     ff::NormArgs k;
-    long long most = n_check;
-    for (int t = 0; t < FF_NORM_TERMS; ++t) {
-        const bool on = t < n_terms;
-        if (on && (terms[t].n < 0 || (terms[t].n > 0 && (!terms[t].num || !terms[t].scale0)))) return FF_ERR_BADARG;
-        k.num[t] = on ? terms[t].num : nullptr; k.sub[t] = on ? terms[t].sub : nullptr;
-        k.s0[t] = on ? terms[t].scale0 : nullptr; k.s1[t] = on ? terms[t].scale1 : nullptr;
-        k.n[t] = on ? terms[t].n : 0;
-        k.vec_ok[t] = ((((uintptr_t)k.num[t]) | ((uintptr_t)k.sub[t]) | ((uintptr_t)k.s0[t]) | ((uintptr_t)k.s1[t])) & 15) == 0;
-        if (k.n[t] > most) most = k.n[t];
-    }
-    k.check_vec_ok = (((uintptr_t)check) & 15) == 0;
-    k.check = check; k.n_check = n_check; k.n_terms = n_terms; k.atol = atol; k.rtol = rtol; k.out = out;
-    k.counter = (unsigned*)workspace;
-    k.partial = (double*)((char*)workspace + 16);
-    long long want = (most / 4 + 255) / 256;              // one 16-byte access per thread and trip
-    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > ff::kNormBlocks ? ff::kNormBlocks : want));
+    const unsigned grid = ff::norm_args_from_terms(k, terms, n_terms, atol, rtol, check, n_check, out, workspace);
+    if (grid == 0) return FF_ERR_BADARG;
     hipLaunchKernelGGL(ff::scaled_rms_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, k);
     return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;
 }

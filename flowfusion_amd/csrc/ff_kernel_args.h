@@ -49,6 +49,11 @@ struct KernelArgs {
     int act_kind;        // FF_ACT_* (read by the run-time-choice instantiations only)
     float act_p0, act_p1;   // parameters of the hidden activation (FF_ACT_LEAKY_RELU / ELU / SOFTPLUS)
     unsigned long long* debug_stamps;   // diagnostic builds only (FF_DEBUG_STAMPS); NULL in the product
+    const int* gate;     // ff_ode_args.gate: device word read at kernel start; 0 = this launch does nothing (NULL = run)
 };
+
+// bits of the status word (ff_ode_args.status)
+constexpr unsigned kStatusNaN = 1u;        // a final state holds a NaN
+constexpr unsigned kStatusBadSlot = 2u;    // an evaluation row named a stage slot this kernel does not keep on chip
 
 } // namespace ff

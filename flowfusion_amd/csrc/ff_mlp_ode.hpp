@@ -465,6 +465,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     constexpr int R4 = DREGS / 4;
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;   // scalar (SMEM) loads
 
+    // launches enqueued ahead of a device-side decision (the adaptive driver, ff_adaptive.hip): a cleared gate word makes
+    // this launch a no-op -- uniform over the grid, read before any barrier
+    if (args.gate && *(const volatile int*)args.gate == 0) return;
+
     const int lane = threadIdx.x & 63;
     const int qd = lane >> T::SHIFT;                 // lane group (k index of the MFMA operands)
     const int col = lane & (TILE - 1);
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     const bool stamp_on = (blockIdx.x == 0 && threadIdx.x == 0 && args.debug_stamps != nullptr);
 #endif
 
+    bool bad_slot = false;
     for (int e = 0; e < args.n_evals; ++e) {
         const int row_byte = e * args.etab_stride * 4;
         HdrPtr hdr = (HdrPtr)(args.etab + (size_t)e * args.etab_stride);
@@ -920,9 +925,14 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             const float v = __builtin_fmaf(a_e, y[r], b_e * net[r]);
             rhs[r] = is_tangent ? 0.f : v;
         }
+        // (a row naming a slot beyond the kSlots on chip is refused: nothing is stored, the status word says so)
+        const bool slot_ok = (unsigned)slot < (unsigned)kSlots;
+        bad_slot |= !slot_ok;
+        if (slot_ok) {
 #pragma unroll
-        for (int j = 0; j < R4; ++j)
-            ks[(slot * R4 + j) * 64] = f32x4{rhs[4 * j], rhs[4 * j + 1], rhs[4 * j + 2], rhs[4 * j + 3]};
+            for (int j = 0; j < R4; ++j)
+                ks[(slot * R4 + j) * 64] = f32x4{rhs[4 * j], rhs[4 * j + 1], rhs[4 * j + 2], rhs[4 * j + 3]};
+        }
         if constexpr (TANGENTS) {
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) kl[s] = (slot == s) ? div : kl[s];
@@ -1032,7 +1042,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
         }
     }
     if (args.status && __any(bad)) {
-        if (lane == 0) atomicOr(args.status, 1u);
+        if (lane == 0) atomicOr(args.status, kStatusNaN);
+    }
+    if (args.status && bad_slot) {
+        if (lane == 0) atomicOr(args.status, kStatusBadSlot);
     }
 }
 

@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
     constexpr int NBUF = (NSL == 4 && DT == 1 && has_four_slot_twin(NP, DT, HW)) ? weight_buffers(NP, 4) : kBuffers;
     typedef const __attribute__((address_space(4))) RowHdr* HdrPtr;
 
+    // a cleared gate word (launches enqueued ahead of a device-side decision: ff_adaptive.hip) makes this launch a no-op
+    if (args.gate && *(const volatile int*)args.gate == 0) return;
+
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -667,6 +670,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
         });
     };
 
+    bool bad_slot = false;
     for (int e = 0; e < args.n_evals; ++e) {
 #ifdef FF_SPLIT_STAMPS
         stamp_on = args.debug_stamps && blockIdx.x == 0 && wv == 0 && (e == 2 || e == 3);
@@ -755,6 +759,10 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
 
         FF_STAMP();
         // ---- right-hand side and stage bookkeeping ------------------------------------------------------------------
+        // (a row naming a slot beyond the NSLOT on chip -- behind them sit the parked stage input and the state -- is
+        // refused: nothing is stored, the status word says so)
+        const bool slot_ok = (unsigned)slot < (unsigned)NSLOT;
+        bad_slot |= !slot_ok;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             float dot = 0.f;
@@ -767,7 +775,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
                     const float v = __builtin_fmaf(a_e, yv[i], b_e * O[t][cb][i]);
                     rhs[i] = is_tangent ? 0.f : v;
                 }
-                ks[SL(slot, cb, t)] = rhs;
+                if (slot_ok) ks[SL(slot, cb, t)] = rhs;
                 if constexpr (TANGENTS) {
                     const f32x4 xv = ks[SL(NSLOT + 1, cb, t)];            // tangent lanes: the probe e
 #pragma unroll
@@ -901,7 +909,10 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
         }
     }
     if (args.status && __any(bad)) {
-        if (lane == 0) atomicOr(args.status, 1u);
+        if (lane == 0) atomicOr(args.status, kStatusNaN);
+    }
+    if (args.status && bad_slot) {
+        if (lane == 0) atomicOr(args.status, kStatusBadSlot);
     }
 }
 

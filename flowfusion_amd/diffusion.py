@@ -27,7 +27,8 @@ import torch
 from torch import nn
 from torch.distributions import Normal
 
-from . import adaptive, generic, solvers
+from . import adaptive, device_adaptive, generic, solvers
+from . import _native
 from . import host_stepper, trace_estimators
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
 
@@ -305,6 +306,27 @@ class ScoreModel(nn.Module):
                                    c_col0=E + m.n_dimensions, act=act, precision=prec)
         return self._fused
 
+    def _device_schedule(self, device):
+        """What the device-side adaptive controller needs to evaluate this model's time-dependent terms itself
+        (``device_adaptive.ScheduleSpec``), or None when it cannot: an SDE class other than the reference's three, or a
+        score network without the MLP's Fourier features.  Scalars that live in buffers are read once per value."""
+        sde, m = self.sde, self.model
+        kind = {VESDE: _native.SCHED_VE, VPSDE: _native.SCHED_VP, SUBVPSDE: _native.SCHED_SUBVP}.get(type(sde))
+        if kind is None or not (hasattr(m, "W") and hasattr(m, "pi") and hasattr(m, "NN")):
+            return None
+        names = ("sigma_min", "sigma_max", "T") if kind == _native.SCHED_VE else ("beta_min", "beta_max", "T")
+        vals = [getattr(sde, n) for n in names] + [m.pi]
+        key = tuple((v.data_ptr(), v._version) if torch.is_tensor(v) else v for v in vals)
+        hit = self.__dict__.get("_dev_sched_scalars")
+        if hit is None or hit[0] != key:
+            hit = (key, [float(v) for v in vals])
+            object.__setattr__(self, "_dev_sched_scalars", hit)
+        p0, p1, p2, pi = hit[1]
+        E = 2 * m.W.numel()
+        w0t, b0 = self._net().time_columns(device, 0, E)
+        emb_w = m.W.detach().to(device, torch.float32).contiguous()
+        return device_adaptive.ScheduleSpec(kind, (p0, p1, p2), bool(self.no_sigma), emb_w, pi, w0t, b0)
+
     def _schedule_inputs(self):
         """Host copies of everything `_schedule` reads (SDE, embedding frequencies, first layer).  Taken once
         per solve: the adaptive driver calls `_schedule` at every attempted step, and each device-to-host copy
@@ -345,8 +367,8 @@ class ScoreModel(nn.Module):
                 f"{what}: gradients through the fused solve are not available (the reference's "
                 "odeint_adjoint branch, diffusion.py:620-629, is out of scope); detach the input")
 
-    def _ode_table(self, t_span, method, options, mode):
-        plan = solvers.plan_ode(t_span, method, options)
+    def _ode_table(self, t_span, method, options, mode, y0=None):
+        plan = solvers.plan_ode(t_span, method, options, y0=y0)
         self._net().require_slots(int(plan.slot.max()) + 1, mode, f"method={method!r}")
         a, b, c1, _ = self._schedule(plan.t_eval, "ode")
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
@@ -364,6 +386,15 @@ class ScoreModel(nn.Module):
                 x = (x - affine["in_shift"]) / affine["in_scale"]
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
+            spec = self._device_schedule(x.device) if x.is_cuda else None
+            if device_adaptive.supported(spec, x):
+                # the whole loop on the device: attempts, error norms, step control, the next attempt's table rows
+                y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]),
+                                                     rtol, atol, options, method, cond=cond, probe=probe)
+                self.last_solver_stats = stats
+                if affine.get("out_scale") is not None:
+                    y = y * affine["out_scale"] + affine["out_shift"]
+                return y, lp
             host = self._schedule_inputs()
             sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             step = net.make_step(sched, sign, mode, x.device, cond=cond, probe=probe)
@@ -377,7 +408,10 @@ class ScoreModel(nn.Module):
             return y, lp
         key = ("score-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode,
                self.no_sigma, self._schedule_key())
-        table = net.cached_table(key, x.device, lambda: self._ode_table(t_span, method, options, mode))
+        if (options or {}).get("grid_constructor") is not None:      # the grid may depend on y0: built per call
+            table = self._ode_table(t_span, method, options, mode, y0=x).to(x.device)
+        else:
+            table = net.cached_table(key, x.device, lambda: self._ode_table(t_span, method, options, mode))
         y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, stage_slots=solvers.resolve_method(method).stages, **affine)
         return y, (lp if mode != MODE_STATE else None)
 

@@ -21,7 +21,7 @@ from typing import List, Optional, Tuple
 import torch
 from torch import nn
 
-from . import adaptive, generic, solvers
+from . import _native, adaptive, device_adaptive, generic, solvers
 from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
 
 _DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
@@ -109,8 +109,8 @@ class _FlowBase(nn.Module):
             c1 = t[:, None] * w0[:, D][None, :] + b0[None, :]
             return torch.zeros_like(t), torch.ones_like(t), c1
 
-    def _table(self, t_span, method, options, mode):
-        plan = solvers.plan_ode(t_span, method, options)
+    def _table(self, t_span, method, options, mode, y0=None):
+        plan = solvers.plan_ode(t_span, method, options, y0=y0)
         self._net().require_slots(int(plan.slot.max()) + 1, mode, f"method={method!r}")
         a, b, c1 = self._schedule(plan.t_eval)
         return solvers.build_table(plan, a, b, c1, self._net().width(mode))
@@ -127,10 +127,19 @@ class _FlowBase(nn.Module):
                 raise AssertionError("affine epilogues are applied by the caller on the adaptive path")
             t = t_span.double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
-            first = net.first_layer_cpu()
-            step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
             # the reference keeps the raw conditional in the solver state (flow.py:779-796, 855-881)
             extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
+            if x.is_cuda and not device_adaptive.host_controller_forced():
+                # the whole loop on the device (device_adaptive.py): xdot = NET([x, t, cond]) -> a = 0, b = 1, c1 = w_t t + b1
+                D = self.target_dimension
+                w0t, b0 = net.time_columns(x.device, D, D + 1)
+                spec = device_adaptive.ScheduleSpec(_native.SCHED_FLOW, (0.0, 0.0, 0.0), True, None, 0.0, w0t, b0)
+                y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]), rtol, atol,
+                                                     options, method, cond=cond, probe=probe, norm_only=extra)
+                self.last_solver_stats = stats
+                return y, lp
+            first = net.first_layer_cpu()
+            step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
             solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
@@ -138,7 +147,10 @@ class _FlowBase(nn.Module):
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
             return y, lp
         key = ("flow-ode", tuple(float(v) for v in t_span), method, repr(sorted((options or {}).items())), mode)
-        table = net.cached_table(key, x.device, lambda: self._table(t_span, method, options, mode))
+        if (options or {}).get("grid_constructor") is not None:      # the grid may depend on y0: built per call
+            table = self._table(t_span, method, options, mode, y0=x).to(x.device)
+        else:
+            table = net.cached_table(key, x.device, lambda: self._table(t_span, method, options, mode))
         y, lp, _ = net.integrate(x, table, mode, cond=cond, probe=probe, stage_slots=solvers.resolve_method(method).stages, **affine)
         return y, (lp if mode != MODE_STATE else None)
 

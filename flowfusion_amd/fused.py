@@ -258,6 +258,19 @@ class FusedNet:
         return step
 
     # -- first layer pieces used by the table builders ---------------------------------------
+    def time_columns(self, device, c0: int, c1: int):
+        """(W1[:, c0:c1] contiguous, bias) of the first layer as fp32 device tensors -- what the device-side adaptive
+        controller multiplies the time features with (ff_adapt_config.w0t / b0).  Cached until a parameter changes."""
+        l0 = self.linears[0]
+        key = (str(device), c0, c1, l0.weight.data_ptr(), l0.weight._version, l0.bias.data_ptr(), l0.bias._version)
+        hit = self.__dict__.get("_time_cols")
+        if hit is None or hit[0] != key:
+            w = l0.weight.detach()[:, c0:c1].to(device, torch.float32).contiguous()
+            b = l0.bias.detach().to(device, torch.float32).contiguous()
+            hit = (key, w, b)
+            self._time_cols = hit
+        return hit[1], hit[2]
+
     def first_layer_cpu(self):
         l0 = self.linears[0]
         return (l0.weight.detach().to("cpu", torch.float32), l0.bias.detach().to("cpu", torch.float32))

@@ -113,7 +113,7 @@ def solve(rhs: Rhs, x: torch.Tensor, t_span: torch.Tensor, method: str, options,
         lp0 = torch.zeros(x.shape[0], device=x.device) if has_lp else None
         y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]), x.detach().to(torch.float32).contiguous(), lp0)
         return y, lp, {"attempts": solver.n_attempts, "accepted": solver.n_accepted, "evaluations": stepper.n_evals}
-    plan = solvers.plan_ode(t_span, method, options)
+    plan = solvers.plan_ode(t_span, method, options, y0=x)
     y, lp = stepper.run_plan(x, plan)
     return y, lp, {"evaluations": stepper.n_evals}
 

@@ -132,11 +132,12 @@ class EvalPlan:
     n_steps: int
 
 
-def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict]) -> EvalPlan:
+def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict], y0=None) -> EvalPlan:
     """Rows for ``odeint(func, y0, t_span, method=method, options=options)`` on a fixed grid.
 
     ``t_span`` is the fp32 two-point tensor the reference builds (e.g. ``[1.0, epsilon]``,
     diffusion.py:611; ``[epsilon, 1.0]`` :727; ``[1.0, 0.0]`` flow.py:282; ``[0.0, 1.0]`` :354).
+    ``y0`` (optional) is handed to a ``grid_constructor``.
     """
     tab = resolve_method(method)
     if tab.stages > MAX_SLOTS:
@@ -145,8 +146,10 @@ def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict]) -> Eval
     step_size = options.pop("step_size", None)
     options.pop("min_step", None)      # adaptive-only knob (the reference's log_prob default passes it)
     # torchdiffeq's other fixed-grid options (FixedGridODESolver.__init__): `grid_constructor(func, y0, t)` returns the
-    # time grid instead of `step_size` (called in solver time: a decreasing span arrives negated; func and y0 are not
-    # known where the table is built and are passed as None), `perturb=True` evaluates a step's first stage at the next
+    # time grid instead of `step_size`.  On a decreasing span torchdiffeq's `_check_inputs` wraps the user's function as
+    # `lambda func, y0, t: -grid_constructor(func, y0, -t)`: the constructor sees and returns REAL (decreasing) times,
+    # the solver works on the negated grid.  `func` is not known where the table is built and is passed as None.
+    # `perturb=True` evaluates a step's first stage at the next
     # representable time after t0 and a stage taken at t1 itself at the one before t1 (right-hand sides with jumps on
     # the grid), `interp` only matters for output times inside a step -- the reference asks for the end points only
     grid_constructor = options.pop("grid_constructor", None)
@@ -162,11 +165,12 @@ def plan_ode(t_span: torch.Tensor, method: str, options: Optional[dict]) -> Eval
     if grid_constructor is not None:
         if step_size is not None:
             raise ValueError("step_size and grid_constructor are mutually exclusive arguments.")
-        grid = torch.as_tensor(grid_constructor(None, None, t_span)).detach().to("cpu", torch.float32).reshape(-1)
+        grid = torch.as_tensor(grid_constructor(None, y0, sign * t_span)).detach().to("cpu", torch.float32).reshape(-1)
+        grid = sign * grid          # solver time
         if grid.numel() < 2 or grid[0] != t_span[0] or grid[-1] != t_span[-1]:
             raise AssertionError("grid_constructor must return a grid that starts at t[0] and ends at t[-1]")
         if not bool((grid[1:] > grid[:-1]).all()):
-            raise ValueError("grid_constructor must return strictly increasing times")
+            raise ValueError("grid_constructor must return times strictly monotonic in the direction of the span")
     else:
         grid = fixed_grid(t_span, step_size)
     if grid.numel() < 2:

@@ -92,6 +92,13 @@ extern "C" {
 #define FF_PREC_BF16X3     1
 #define FF_PREC_BF16X2     2
 
+/* bits OR-ed into ff_ode_args.status by a launch */
+#define FF_STATUS_NAN      1u   /* a final state holds a NaN                                */
+#define FF_STATUS_BAD_SLOT 2u   /* an evaluation row named a stage slot the kernel does not
+                                   keep on chip (>= FF_MAX_SLOTS; >= 4 for the plans and twins
+                                   with four slots): that row's right-hand side was NOT stored,
+                                   the results are invalid                                  */
+
 /* evaluation-row flag bits (word 3 of the row header) */
 #define FF_ROW_STEP_END    1u   /* after this evaluation: y += sum_s cout[s] * k[s]        */
 #define FF_ROW_NOISE       2u   /* after the step update: y += gn * noise[noise_index]     */
@@ -129,7 +136,7 @@ typedef struct ff_ode_args {
     const float* in_scale;   /* [dim] or NULL                                              */
     const float* out_scale;  /* [dim] or NULL: x_out = y * out_scale + out_shift           */
     const float* out_shift;  /* [dim] or NULL                                              */
-    uint32_t*    status;     /* device word, OR-ed with 1 if any final state is NaN; NULL ok */
+    uint32_t*    status;     /* device word, OR-ed with FF_STATUS_* bits; NULL ok                */
     int64_t      batch;      /* number of samples                                          */
     int64_t      noise_stride; /* floats between consecutive noise slabs (>= batch*dim)    */
     int32_t      n_evals;    /* rows in etab                                               */
@@ -178,10 +185,15 @@ typedef struct ff_ode_args {
                                 depends on the divergence, so one launch can integrate a whole fixed-grid table and
                                 hand back everything the Hutch++ / XTrace estimators need; they are then evaluated
                                 for all rows at once and combined with the tableau's weights by the caller. */
-    int32_t      stage_slots; /* optional hint: stage slots the table uses (highest slot index + 1, <= FF_MAX_SLOTS); 0 = unknown.
+    int32_t      stage_slots; /* stage slots the table uses (highest slot index + 1, <= FF_MAX_SLOTS); 0 = unknown.
                                  Plans whose kernel keeps fewer slots on chip than FF_MAX_SLOTS (FF_PREC_BF16X2 with dim > 16:
-                                 4) require the table to stay within them; for the others a hint <= 4 lets the launcher pick a
-                                 twin that trades unused slots for occupancy.  Results do not depend on the hint. */
+                                 4) require the table to stay within them (a larger value is FF_ERR_UNSUPPORTED); for the others
+                                 a value <= 4 lets the launcher pick a twin that trades unused slots for occupancy.  The value is
+                                 a PROMISE: a row that names a slot the chosen kernel does not keep is refused by the kernel
+                                 (FF_STATUS_BAD_SLOT, nothing stored) -- a wrong hint is an error, not a no-op.  With a correct
+                                 hint the results do not depend on it. */
+    const int32_t* gate;     /* optional DEVICE word read when the kernel starts: 0 = this launch does nothing.  For launches
+                                enqueued ahead of a decision taken on the device (ff_mlp_ode_adaptive); NULL = run. */
 } ff_ode_args;
 
 /* Library / build identification: returns e.g. "flowfusion_amd 0.1 gfx950". */
@@ -306,6 +318,126 @@ typedef struct ff_norm_term {
 size_t ff_scaled_rms_workspace_bytes(void);
 int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float atol, float rtol, const float* check,
                   int64_t n_check, float* out, void* workspace, void* hip_stream);
+
+/* ---- adaptive embedded Runge-Kutta solves with the step control ON THE DEVICE (csrc/ff_adaptive.hip) ---------
+ *
+ * Replaces `odeint(func, state, t, method="dopri5" | "bosh3" | "fehlberg2" | "adaptive_heun", rtol=, atol=, options=)`
+ * -- the reference's DEFAULT solver at every call site (diffusion.py:572,631-639; 649,744-752; 762; flow.py:299-303,
+ * 313,371-382) -- including torchdiffeq's batch-global step control: `_select_initial_step`, `_compute_error_ratio`
+ * (mixed norm over the tuple state), accept / reject, `_optimal_step_size`, min / max step clamps, the fourth-order dense
+ * output at t[-1].  One attempted step is three launches enqueued back to back with NO host round trip:
+ *     the fused attempt (ff_mlp_ode_launch semantics, gated by ff_adapt_state.active)
+ *  -> norms + controller (one reduction launch; its last block decides, advances (t, dt) and writes the NEXT attempt's
+ *     evaluation rows: stage times, the SDE schedule scalars a_e / b_e and the first-layer time part c1_e, computed in
+ *     fp32 in the reference's operation order: diffusion.py:276-278,905,1131,1316; MLP.forward :109-113; flow.py:112-118)
+ *  -> commit (an accepted step's (y1, f1, lp1, fl1) become the current state).
+ * The host enqueues a chunk of attempts, then reads ff_adapt_state once; attempts behind the end of the solve are no-ops.
+ */
+#define FF_SCHED_FLOW   0   /* flows: a = 0, b = 1, c1 = w_t t + b1 (flow.py:112-118)                       */
+#define FF_SCHED_VE     1   /* VESDE (diffusion.py:818-1003):    p = {sigma_min, sigma_max, T}               */
+#define FF_SCHED_VP     2   /* VPSDE (diffusion.py:1006-1180):   p = {beta_min, beta_max, T}                 */
+#define FF_SCHED_SUBVP  3   /* SUBVPSDE (diffusion.py:1183-1366): p = {beta_min, beta_max, T}                */
+
+#define FF_ADAPT_OK            0
+#define FF_ADAPT_ERR_UNDERFLOW 1   /* torchdiffeq: AssertionError "underflow in dt {dt}" (state.dt holds it)   */
+#define FF_ADAPT_ERR_NONFINITE 2   /* torchdiffeq: "non-finite values in state `y`"                            */
+#define FF_ADAPT_ERR_MAXSTEPS  3   /* torchdiffeq: "max_num_steps exceeded"                                     */
+
+#define FF_ADAPT_MAX_PASSES    8   /* unit-tangent passes of one attempt (FF_MODE_EXACT with dim + 1 > tile)    */
+
+/* Controller state: 128 bytes of DEVICE memory, written by the controller, read back by the host. */
+typedef struct ff_adapt_state {
+    double  t;           /* solver time reached: the end of the last accepted step (rk_state.t1)            */
+    double  dt;          /* step of the next attempt (clamped to [min_step, max_step])                      */
+    double  t_prev;      /* start of the last accepted step (rk_state.t0)                                   */
+    double  dt_prev;     /* its length                                                                      */
+    double  t_end;       /* where the solve stops (solver time: a decreasing span is solved negated)        */
+    double  h0;          /* initial-step rule: the trial step                                               */
+    double  d0;          /* ... the norm of the scaled state                                                */
+    double  d1;          /* ... the norm of the scaled derivative                                           */
+    int32_t active;      /* gate of the launches that follow: 1 = attempts run                              */
+    int32_t commit;      /* 1 = the latest attempt was accepted and is not the last: commit adopts it       */
+    int32_t done;        /* the solve reached t_end: the buffers hold the last accepted step                */
+    int32_t error;       /* FF_ADAPT_ERR_*                                                                  */
+    int32_t n_attempts;
+    int32_t n_accepted;
+    int32_t n_steps;     /* loop iterations (torchdiffeq counts them against max_num_steps)                 */
+    int32_t reserved0;
+    float   last_ratio;  /* error ratio of the latest attempt                                               */
+    float   reserved1[7];
+} ff_adapt_state;
+
+/* The embedded pair, the tolerances and the time-dependent part of the right-hand side (HOST struct). */
+typedef struct ff_adapt_config {
+    int32_t n_stages;    /* stages including the first-same-as-last one, 2 .. FF_MAX_SLOTS                  */
+    int32_t order;       /* order of the pair (torchdiffeq `order`): dopri5 5, bosh3 3, fehlberg2 / adaptive_heun 2 */
+    float   alpha[FF_MAX_SLOTS - 1];        /* stage i + 1 sits at t0 + alpha[i] dt (exactly t1 when alpha[i] == 1) */
+    float   beta[FF_MAX_SLOTS - 1][8];      /* ... on y0 + dt sum_j beta[i][j] k_j                           */
+    float   c_sol[8];    /* y1 = y0 + dt sum_j c_sol[j] k_j                                                 */
+    float   c_mid[8];    /* dense-output midpoint                                                           */
+    float   c_err[8];    /* error estimate                                                                  */
+    float   rtol, atol;
+    double  min_step, max_step;             /* torchdiffeq options (0, +inf by default)                      */
+    double  first_step;  /* option first_step; NaN = torchdiffeq's `_select_initial_step`                   */
+    int32_t max_num_steps;
+    int32_t sched;       /* FF_SCHED_*                                                                      */
+    int32_t no_sigma;    /* ScoreModel(no_sigma=): the network output is NOT divided by sigma(t) (diffusion.py:268-272) */
+    float   sign;        /* +1, or -1 for a decreasing span (solved in -t with the right-hand side negated)  */
+    double  p[4];        /* schedule parameters (FF_SCHED_*)                                                */
+    const float* emb_w;  /* DEVICE [n_emb]: Gaussian-Fourier frequencies W (MLP.W, diffusion.py:73-76); NULL for flows */
+    int32_t n_emb;
+    float   pi;          /* MLP.pi as the model holds it (fp32)                                             */
+    const float* w0t;    /* DEVICE [h_real][n_tcols]: the first layer's time columns ([sin | cos] features, or the
+                            single t column of a flow), row-major                                           */
+    const float* b0;     /* DEVICE [h_real]: the first layer's bias                                         */
+    int32_t h_real;      /* rows of the first layer (<= plan.width; c1 is zero-padded to the width)          */
+    int32_t n_tcols;     /* 2 * n_emb, or 1 for flows                                                        */
+} ff_adapt_config;
+
+/* Work buffers (all DEVICE memory owned by the caller; [B] = batch, [B, D] = batch x dim floats). */
+typedef struct ff_adapt_buffers {
+    float* y;            /* [B, D] in: the initial state; during the solve: the current state               */
+    float* f0;           /* [B, D] derivative at the current state (FSAL)                                   */
+    float* lp;           /* [B]    integrated divergence (modes 1, 2; in: its initial value) or NULL        */
+    float* fl0;          /* [B]    its derivative or NULL                                                   */
+    float* aux[FF_MAX_AUX];      /* [B, D] each: proposal y1, last stage f1, dense-output midpoint, error estimate */
+    float* aux_lp[FF_MAX_AUX];   /* [B] each, or NULL                                                       */
+    float* aux_lp_pass;  /* [n_passes][FF_MAX_AUX][B] partial divergences when n_passes > 1, else NULL      */
+    float* scratch_x;    /* [B, D]                                                                          */
+    float* scratch_lp;   /* [B] or NULL                                                                     */
+    float* etab;         /* [FF_MAX_SLOTS + 1][FF_ROW_HDR + plan.width] evaluation rows, written by the controller */
+    float* out_y;        /* [B, D] the solution at t_end (dense output of the last step)                    */
+    float* out_lp;       /* [B] or NULL                                                                     */
+    ff_adapt_state* state;
+    void*  norm_workspace;       /* ff_scaled_rms_workspace_bytes() bytes, first 16 zero                    */
+    const float* norm_only[2];   /* components the reference carries in the solver state with a zero derivative (the raw */
+    int64_t norm_only_n[2];      /* `conditional` of ConditionalODEFlow, flow.py:779-796): they enter d0 of the initial step */
+    int32_t n_passes;            /* 1, or the unit-tangent passes of FF_MODE_EXACT                          */
+    int32_t pass_first[FF_ADAPT_MAX_PASSES];
+    int32_t pass_count[FF_ADAPT_MAX_PASSES];
+} ff_adapt_buffers;
+
+#define FF_ADAPT_START   1   /* initialise the state, evaluate f(t0, y), choose the first step              */
+#define FF_ADAPT_FINISH  2   /* evaluate the dense output at t_end into out_y / out_lp (a no-op until done)  */
+
+/*
+ * Enqueue on hip_stream: [FF_ADAPT_START:] the start-up launches, then `n_attempts` attempted steps, then
+ * [FF_ADAPT_FINISH:] the dense output.  `base` supplies cond / probe / wpack / mode / batch (its state, table, aux and
+ * adaptive fields are ignored).  t0 / t_end are solver times (already negated for a decreasing span) and only read with
+ * FF_ADAPT_START.  Nothing is read back: the caller copies *buffers->state to the host when it wants to know (done,
+ * error, counters) and calls again with what = 0 or FF_ADAPT_FINISH while `done` and `error` are both zero.
+ */
+int ff_mlp_ode_adaptive(const ff_mlp_plan_t* plan, const ff_ode_args* base, const ff_adapt_config* config,
+                        const ff_adapt_buffers* buffers, double t0, double t_end, int32_t what, int32_t n_attempts,
+                        void* hip_stream);
+
+/* The controller's arithmetic on the HOST (tests without a GPU): one evaluation row for real time `t_real` -- a_e, b_e
+ * (already multiplied by config->sign) and c1[config->h_real] -- with emb_w / w0t / b0 read as HOST pointers. */
+int ff_adapt_host_row(const ff_adapt_config* config, float t_real, float* a_out, float* b_out, float* c1_out);
+/* ... and one controller transition: `phase` 1 = after the initial-step norms d0 (norms[0]) and d1 (norms[1]), 2 = after
+ * d2 (norms[0] = the unscaled norm), 3 = after an attempted step (norms[0] = error ratio, norms[1] != 0: non-finite y1),
+ * 4 = first_step given.  Updates *state; returns 1 if an attempt must follow. */
+int ff_adapt_host_transition(const ff_adapt_config* config, ff_adapt_state* state, int32_t phase, const float* norms);
 
 #ifdef __cplusplus
 }

@@ -419,16 +419,22 @@ def odeint_fixed(func: Callable, y0: Tuple[torch.Tensor, ...], t: torch.Tensor, 
     options = dict(options or {})
     step_size = options.get("step_size", None)
     step = _STEPPERS[method]
+    grid_constructor = options.get("grid_constructor")
     if bool(t[0] > t[-1]):
         t = -t
         base = func
         func = lambda tt, yy: tuple(-f for f in base(-tt, yy))
-    # FixedGridODESolver's other options: grid_constructor(func, y0, t) in place of step_size (solver time), and
+        if grid_constructor is not None:
+            # torchdiffeq `_check_inputs`: options['grid_constructor'] = lambda func, y0, t: -_grid_constructor(func, y0, -t)
+            # -- the user's constructor sees and returns real (decreasing) times
+            user_gc = grid_constructor
+            grid_constructor = lambda f, y, tt: -user_gc(f, y, -tt)
+    # FixedGridODESolver's other options: grid_constructor(func, y0, t) in place of step_size, and
     # perturb: the step's first evaluation at nextafter(t0, +inf), an evaluation taken at t1 itself at nextafter(t1, -inf)
     # (_PerturbFunc wraps the already reversed function, so the shift is applied in solver time)
-    if options.get("grid_constructor") is not None:
+    if grid_constructor is not None:
         assert step_size is None, "step_size and grid_constructor are mutually exclusive arguments."
-        grid = options["grid_constructor"](func, y0, t)
+        grid = grid_constructor(func, y0, t)
         assert grid[0] == t[0] and grid[-1] == t[-1]
     else:
         grid = t if step_size is None else grid_from_step_size(t, step_size)
@@ -476,6 +482,11 @@ _ADAPTIVE_TABLEAUX = {
 }
 
 
+# attempts / accepted steps of the latest adaptive solve (kept up to date while it runs, so a solve that ends in
+# torchdiffeq's "underflow in dt" assertion still says how far it got)
+last_adaptive_stats = {"attempts": 0, "accepted": 0}
+
+
 def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri5"):
     """Adaptive dopri5 (or another embedded pair of `_ADAPTIVE_TABLEAUX`) from ``t[0]`` to ``t[-1]`` for a tuple state;
     returns the tuple at ``t[-1]``.
@@ -520,6 +531,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     y, f = tuple(y0), f0
     t_lo = t_hi = t0
     last = None
+    last_adaptive_stats.update(attempts=0, accepted=0)
     while t[-1] > t_hi:
         dt = dt.clamp(min_step, max_step)                         # every attempt starts from a clamped step
         ta, tb = t_hi, t_hi + dt
@@ -536,6 +548,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
         err = comb(ks, C_ERR, dt32)
         tol = tuple(atol + rtol * torch.max(a.abs(), b.abs()) for a, b in zip(y, y1))
         ratio = _tuple_norm([e / s for e, s in zip(err, tol)]).abs()
+        last_adaptive_stats["attempts"] += 1
         accept = bool(ratio <= 1)
         if dt > max_step:
             accept = False
@@ -544,6 +557,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
         if accept:
             ymid = tuple(a + b for a, b in zip(y, comb(ks, C_MID, dt32)))
             last = (ta, tb, dt32, y, y1, ymid, f, f1)
+            last_adaptive_stats["accepted"] += 1
             t_lo, t_hi = ta, tb
             y, f = y1, f1
         ratio = ratio.double()

@@ -24,12 +24,34 @@ int main(void)
     OFF(ff_ode_args, kl1_in); OFF(ff_ode_args, dlogp_in); OFF(ff_ode_args, aux_out); OFF(ff_ode_args, aux_lp_out);
     OFF(ff_ode_args, n_aux); OFF(ff_ode_args, rng_noise_base); OFF(ff_ode_args, rng_seed);
     OFF(ff_ode_args, rng_sample_offset); OFF(ff_ode_args, jac_out); OFF(ff_ode_args, jac_all); OFF(ff_ode_args, stage_slots);
+    OFF(ff_ode_args, gate);
     SZ(ff_combine_args);
     OFF(ff_combine_args, x); OFF(ff_combine_args, k); OFF(ff_combine_args, coef); OFF(ff_combine_args, x_coef);
     OFF(ff_combine_args, out); OFF(ff_combine_args, n);
     SZ(ff_norm_term);
     OFF(ff_norm_term, num); OFF(ff_norm_term, sub); OFF(ff_norm_term, scale0); OFF(ff_norm_term, scale1); OFF(ff_norm_term, n);
     printf("normws %zu\n", ff_scaled_rms_workspace_bytes());
+    SZ(ff_adapt_state);
+    OFF(ff_adapt_state, t); OFF(ff_adapt_state, dt); OFF(ff_adapt_state, t_prev); OFF(ff_adapt_state, dt_prev);
+    OFF(ff_adapt_state, t_end); OFF(ff_adapt_state, h0); OFF(ff_adapt_state, d0); OFF(ff_adapt_state, d1);
+    OFF(ff_adapt_state, active); OFF(ff_adapt_state, commit); OFF(ff_adapt_state, done); OFF(ff_adapt_state, error);
+    OFF(ff_adapt_state, n_attempts); OFF(ff_adapt_state, n_accepted); OFF(ff_adapt_state, n_steps);
+    OFF(ff_adapt_state, reserved0); OFF(ff_adapt_state, last_ratio); OFF(ff_adapt_state, reserved1);
+    SZ(ff_adapt_config);
+    OFF(ff_adapt_config, n_stages); OFF(ff_adapt_config, order); OFF(ff_adapt_config, alpha); OFF(ff_adapt_config, beta);
+    OFF(ff_adapt_config, c_sol); OFF(ff_adapt_config, c_mid); OFF(ff_adapt_config, c_err); OFF(ff_adapt_config, rtol);
+    OFF(ff_adapt_config, atol); OFF(ff_adapt_config, min_step); OFF(ff_adapt_config, max_step);
+    OFF(ff_adapt_config, first_step); OFF(ff_adapt_config, max_num_steps); OFF(ff_adapt_config, sched);
+    OFF(ff_adapt_config, no_sigma); OFF(ff_adapt_config, sign); OFF(ff_adapt_config, p); OFF(ff_adapt_config, emb_w);
+    OFF(ff_adapt_config, n_emb); OFF(ff_adapt_config, pi); OFF(ff_adapt_config, w0t); OFF(ff_adapt_config, b0);
+    OFF(ff_adapt_config, h_real); OFF(ff_adapt_config, n_tcols);
+    SZ(ff_adapt_buffers);
+    OFF(ff_adapt_buffers, y); OFF(ff_adapt_buffers, f0); OFF(ff_adapt_buffers, lp); OFF(ff_adapt_buffers, fl0);
+    OFF(ff_adapt_buffers, aux); OFF(ff_adapt_buffers, aux_lp); OFF(ff_adapt_buffers, aux_lp_pass);
+    OFF(ff_adapt_buffers, scratch_x); OFF(ff_adapt_buffers, scratch_lp); OFF(ff_adapt_buffers, etab);
+    OFF(ff_adapt_buffers, out_y); OFF(ff_adapt_buffers, out_lp); OFF(ff_adapt_buffers, state);
+    OFF(ff_adapt_buffers, norm_workspace); OFF(ff_adapt_buffers, norm_only); OFF(ff_adapt_buffers, norm_only_n);
+    OFF(ff_adapt_buffers, n_passes); OFF(ff_adapt_buffers, pass_first); OFF(ff_adapt_buffers, pass_count);
 
     /* plan + packed size for BASELINE config 2's network, from C */
     const int hidden[4] = {256, 256, 256, 256};
@@ -42,6 +64,7 @@ int main(void)
     printf("badmode rc %d\n", rc);
     ff_ode_args a = {0};
     printf("nullargs rc %d\n", ff_mlp_ode_launch(&plan, &a, NULL));
+    printf("nulladapt rc %d\n", ff_mlp_ode_adaptive(&plan, &a, NULL, NULL, 0.0, 1.0, FF_ADAPT_START, 1, NULL));
     printf("version %s\n", ff_version());
     return 0;
 }

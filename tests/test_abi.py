@@ -72,6 +72,9 @@ def test_header_is_c11_and_layouts_match_both_ctypes_mirrors(tmp_path, built_lib
         "ff_ode_args": (_native.OdeArgs, ns["_Args"]),
         "ff_combine_args": (_native.CombineArgs,),
         "ff_norm_term": (_native.NormTerm,),
+        "ff_adapt_state": (_native.AdaptState,),
+        "ff_adapt_config": (_native.AdaptConfig,),
+        "ff_adapt_buffers": (_native.AdaptBuffers,),
     }
     for cname, structs in mirrors.items():
         fields_c = {f for (s, f) in offsets if s == cname}
@@ -87,6 +90,7 @@ def test_header_is_c11_and_layouts_match_both_ctypes_mirrors(tmp_path, built_lib
     assert int(other["wpack_floats"].split()[1]) == built_library.ff_mlp_wpack_floats(ctypes.byref(p))
     assert other["spw"].split()[1] == "64"
     assert other["badmode"].split()[2] == "-1" and other["nullargs"].split()[2] == "-1"
+    assert other["nulladapt"].split()[2] == "-1"
     assert "gfx950" in other["version"]
 
 
@@ -94,7 +98,8 @@ def test_kernel_args_header_matches_public_header():
     """The public constants the kernels are compiled against (csrc/ff_kernel_args.h, ff_layout.h) are static_assert-ed
     against include/flowfusion_amd.h in ff_api.cpp; check the assertion lines are still there."""
     src = (ROOT / "flowfusion_amd" / "csrc" / "ff_api.cpp").read_text()
-    for needle in ("FF_MAX_SLOTS == ff::kSlots", "FF_MAX_AUX == ff::kAux", "FF_ROW_HDR * 4 == sizeof(ff::RowHdr)"):
+    for needle in ("FF_MAX_SLOTS == ff::kSlots", "FF_MAX_AUX == ff::kAux", "FF_ROW_HDR * 4 == sizeof(ff::RowHdr)",
+                   "FF_STATUS_NAN == ff::kStatusNaN", "sizeof(ff_adapt_state) == 128"):
         assert needle in src
 
 

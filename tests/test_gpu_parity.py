@@ -260,6 +260,30 @@ def test_grid_constructor_and_perturb_on_the_gpu():
     assert _state_err(f.sample(xT.to(DEV), method="heun3", options=opts), fo.sample(xT, None, "heun3", opts)) < STATE_TOL
 
 
+def test_grid_constructor_sees_real_times_on_a_decreasing_span():
+    """torchdiffeq hands a user's grid_constructor the REAL span of a decreasing solve and negates what it returns
+    (`_check_inputs`: ``lambda func, y0, t: -gc(func, y0, -t)``).  Every sampling call of the reference is decreasing
+    (diffusion.py:611, flow.py:282), so an asymmetric grid written in real time -- [1, .5, .1, eps] -- must be taken as
+    is: product and oracle walk exactly those times, and y0 reaches the constructor."""
+    sm, so32, _ = _seeded_score_model(6, 0, [128, 128], "VPSDE", True, 271)
+    eps = float(sm.sde.epsilon)
+    seen = {}
+
+    def explicit(func, y0, t):
+        seen["t"], seen["y0"] = [float(v) for v in t], y0
+        return torch.tensor([1.0, 0.5, 0.1, float(t[-1])], dtype=t.dtype)
+
+    base = torch.randn(90, 6)
+    opts = {"grid_constructor": explicit}
+    for method in ("euler", "rk4"):
+        x0, _ = sm.sample_ode_from_base(base.to(DEV), method=method, options=opts)
+        assert seen["t"][0] == 1.0 and abs(seen["t"][1] - eps) < 1e-9 and tuple(seen["y0"].shape) == (90, 6)
+        assert _state_err(x0, so32.sample_ode_from_base(base, None, method, opts)) < STATE_TOL, method
+    # the same grid through an explicit three-step table equals the constructor's result bit for bit
+    tab = sm._ode_table(torch.tensor([1.0, eps]), "rk4", opts, 0)
+    assert torch.equal(tab[::4, 0] != 0, torch.ones(3, dtype=torch.bool)) and tab.shape[0] == 12
+
+
 def test_networks_outside_the_compiled_envelope_solve_through_the_module_path():
     """The reference puts no limit on width, dimension or activation (diffusion.py:59-72, flow.py:61-74).  Outside the
     compiled kernels' envelope the solve stays on the GPU -- network evaluated by torch, stepping / error control /

@@ -47,8 +47,8 @@ def test_plan_selection_and_errors(built_library):
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
     p = _native.make_plan(48, 0, [256, 256], MODE_EXACT)          # many dimensions on a 256-wide net stay 256 wide
     assert (p.tile, p.width, p.dregs) == (16, 256, 16)
-    p = _native.make_plan(6, 24, [128, 128], MODE_HUTCH)          # more than 16 conditional inputs: the catch-all
-    assert (p.tile, p.width, p.cregs) == (16, 512, 8)
+    p = _native.make_plan(6, 24, [128, 128], MODE_HUTCH)          # more than 16 conditional inputs: the 256-wide catch-all
+    assert (p.tile, p.width, p.cregs) == (16, 256, 8)
     p = _native.make_plan(64, 0, [512] * 5, MODE_STATE)           # BASELINE config 4: 16x16x4 kernels
     assert (p.tile, p.width, p.dregs) == (16, 512, 16)
     p = _native.make_plan(64, 0, [512] * 5, MODE_EXACT)           # exact trace: passes of tile-1 tangents
@@ -61,7 +61,7 @@ def test_plan_selection_and_errors(built_library):
         _native.make_plan(4, 65, [64], MODE_STATE)                # more conditional inputs than any compiled kernel
     # beyond 512 wide / 64 dimensions / 32 conditional inputs: the wide catch-alls (a tile per workgroup at every batch size)
     p = _native.make_plan(64, 0, [1024] * 2, MODE_STATE)
-    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 1024, 16, 8) and _native.kernel_name(p).endswith("_wide")
+    assert (p.tile, p.width, p.dregs, p.cregs) == (16, 1024, 32, 16) and _native.kernel_name(p).endswith("_wide")
     assert _native.samples_per_workgroup(p, MODE_STATE) == 16
     p = _native.make_plan(100, 40, [300], MODE_HUTCH)
     assert (p.width, p.dregs, p.cregs) == (1024, 32, 16) and _native.samples_per_workgroup(p, MODE_HUTCH) == 8
@@ -118,7 +118,8 @@ def test_plan_ode_rows():
 
 def test_grid_constructor_and_perturb_options(built_library):
     """torchdiffeq's other fixed-grid options (FixedGridODESolver): ``grid_constructor(func, y0, t)`` in place of
-    ``step_size`` (seen in solver time: a decreasing span arrives negated) and ``perturb=True`` (first stage one ulp
+    ``step_size`` (on a decreasing span torchdiffeq's `_check_inputs` wraps it as ``-gc(func, y0, -t)``: the user's
+    function sees and returns REAL, decreasing times) and ``perturb=True`` (first stage one ulp
     after t0, a stage taken at t1 one ulp before it) -- rows checked word by word, then the kernel's semantics on the
     CPU against the oracle's restatement of the same options."""
     seen = {}
@@ -132,8 +133,8 @@ def test_grid_constructor_and_perturb_options(built_library):
 
     span = torch.tensor([1.0, 1e-3])
     plan = solvers.plan_ode(span, "rk4", {"grid_constructor": chebyshev_like, "perturb": True})
-    assert seen["t"].tolist() == [-1.0, -0.0010000000474974513]            # the reversed span
-    g = chebyshev_like(None, None, -span)
+    assert seen["t"].tolist() == [1.0, 0.0010000000474974513]              # the real, decreasing span
+    g = -chebyshev_like(None, None, span)                                  # solver time
     assert plan.sign == -1.0 and plan.n_steps == 8
     te = -plan.t_eval.view(8, 4)                                           # back to solver time
     assert torch.equal(te[:, 0], torch.nextafter(g[:-1], g[:-1] + 1)) and torch.equal(te[:, 3], torch.nextafter(g[1:], g[1:] - 1))
@@ -147,6 +148,23 @@ def test_grid_constructor_and_perturb_options(built_library):
         solvers.plan_ode(span, "euler", {"grid_constructor": lambda f, y, t: t * 0.5})
     with pytest.raises(ValueError, match="interpolation"):
         solvers.plan_ode(span, "euler", {"interp": "nope"})
+    # an asymmetric grid written in REAL time on a decreasing span (what a torchdiffeq user writes): accepted as is,
+    # the stage times of the plan are the real times, y0 is handed through
+    got = {}
+
+    def explicit(func, y0, t):
+        got["y0"] = y0
+        return torch.tensor([1.0, 0.5, 0.1, float(t[-1])])
+
+    y0 = torch.zeros(3, 2)
+    pe = solvers.plan_ode(span, "euler", {"grid_constructor": explicit}, y0=y0)
+    assert got["y0"] is y0 and pe.sign == -1.0 and pe.n_steps == 3
+    assert pe.t_eval.tolist() == [1.0, 0.5, 0.10000000149011612]
+    torch.testing.assert_close(pe.cout[:, 0], torch.tensor([0.5, 0.4, 0.1 - 1e-3]), rtol=1e-6, atol=0)
+    with pytest.raises(ValueError, match="monotonic"):
+        solvers.plan_ode(span, "euler", {"grid_constructor": lambda f, y, t: torch.tensor([1.0, 0.2, 0.5, float(t[-1])])})
+    inc = solvers.plan_ode(torch.tensor([1e-3, 1.0]), "euler", {"grid_constructor": lambda f, y, t: torch.tensor([float(t[0]), 0.3, 1.0])})
+    assert inc.sign == 1.0 and inc.t_eval.tolist() == [0.0010000000474974513, 0.30000001192092896]
 
     torch.manual_seed(2)
     sm = D.ScoreModel(D.MLP(5, 2, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
@@ -343,9 +361,10 @@ def test_activation_plumbing_matches_oracle(act, built_library):
     sm = D.ScoreModel(D.MLP(5, 2, 8, [48, 64], activation=act), D.VESDE(), no_sigma=False).eval()
     net = sm._net()
     plan = _native.plan_words(net.plan(MODE_EXACT))
-    # a kernel with THIS activation compiled in (name suffix _a<FF_ACT code>)
+    # the plan carries THIS activation; the kernel either has it compiled in (name suffix _a<FF_ACT code>, FF_BUILD_FULL)
+    # or chooses it at run time from the plan (suffix _a9: one instantiation per width and mode since round 3)
     assert plan[8] == net.act[0] != _native.ACT_SILU
-    assert built_library.ff_kernel_name(plan[6]).endswith(b"_a%d" % net.act[0])
+    assert built_library.ff_kernel_name(plan[6]).endswith((b"_a%d" % net.act[0], b"_a9"))
     so = O.ScoreOracle(O.mlp_params_from_state_dict(sm.state_dict()), O.VE(dtype=torch.float64), no_sigma=False,
                        dtype=torch.float64, activation=act)
     x0, cond = torch.randn(7, 5), torch.randn(7, 2)
