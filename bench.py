@@ -12,6 +12,11 @@ standard-normal base samples resident in HBM.  One "step" = one full solve of th
 
 N > 1: one process per GPU, every rank solves its own 2^20-sample shard (weak scaling) and the
 shards meet in one RCCL all-gather per step, inside the timed region.  Rank 0 prints ONE JSON line.
+After the timed loop the N > 1 run also solves the two BASELINE configurations that are WORDED for a
+node -- configs[3] (64-dim flow, 2^22 rows sharded N ways) and configs[4] (conditional 32-dim VE,
+1000-step Euler-Maruyama, 2^20 rows sharded N ways, noise keyed by the global row) -- one all-gather
+each, under `extra_configs`, and checks that a rank's rows equal a single-launch solve of those rows
+(`rank_invariant`).  Host threads are capped at usable_cores() // N per rank.
 
 `roofline`: the path is a dense fp32 contraction (1.3e6 FLOP per algorithmic HBM byte), so the
 bounding roofline is the fp32 MFMA peak; `achieved` = algorithmic FLOPs of one launch (2 x MACs of
@@ -233,7 +238,39 @@ def extra_configs(device):
                 "wall_ms_one_wavefront_kernel": 1e3 * lat["0"], "speedup_of_cooperative_twin": lat["0"] / lat[None],
                 "dtype": "f32", "note": "below ~3/4 of a chip's worth of tiles the launcher gives each tile to a workgroup "
                 "(rows of a layer split over its 4 wavefronts, LDS exchange per layer); bitwise the same results"})
-    del sm, net, x0, xe, zs
+    # --- the reference's DEFAULT log_prob arguments at scale: adaptive dopri5 (atol = rtol = 1e-4, min_step 1e-6) with the
+    # Hutchinson probe and with the exact trace (two unit-tangent passes per attempted step), 2^18 points of config 2's model.
+    # The whole loop runs on the device (csrc/ff_adaptive.hip); FF_HOST_CONTROLLER=1 is round 2's host loop, for the record.
+    Bd = 1 << 18
+    xd = x0[:Bd].contiguous()
+    for hutch in (True, False):
+        sm.hutch = hutch
+        entry = {"workload": "default-argument log_prob (adaptive dopri5, atol = rtol = 1e-4, min_step 1e-6), 16-dim VP-SDE 4x256, "
+                             + ("Hutchinson probe" if hutch else "exact trace (reference default divergence)") + ", batch 2^18",
+                 "unit": "log-probs/s", "dtype": "f32", "kernel": name_of(sm._net(), 1 if hutch else 2)}
+        try:
+            sm.log_prob(xd[:4096].contiguous())
+            for tag, env in (("device_controller", None), ("host_controller", "1")):
+                if env is None:
+                    os.environ.pop("FF_HOST_CONTROLLER", None)
+                else:
+                    os.environ["FF_HOST_CONTROLLER"] = env
+                _, wall, kms = _timed(lambda: sm.log_prob(xd), device)
+                st = dict(sm.last_solver_stats)
+                cols = 2 if hutch else DIM + 1
+                flop = cols * 2.0 * mac_per_eval(DIM, UNITS) * (6 * st["attempts"] + 2) * Bd
+                entry[tag] = {"wall_ms": 1e3 * wall, "hip_event_ms": kms, "value": Bd / wall, **st,
+                              "achieved_TFLOPs_algorithmic": flop / wall / 1e12,
+                              "frac_of_fp32_mfma_peak": flop / wall / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+            entry["value"] = entry["device_controller"]["value"]
+            entry["speedup_vs_host_controller"] = entry["host_controller"]["wall_ms"] / entry["device_controller"]["wall_ms"]
+        except RuntimeError as e:
+            entry["error"] = str(e)
+        finally:
+            os.environ.pop("FF_HOST_CONTROLLER", None)
+        out.append(entry)
+    sm.hutch = False
+    del sm, net, x0, xe, zs, xd
     # --- the reference's notebook shape (BASELINE configs[0] as demo_diffusion.ipynb has it): 2-D VE, 3x128, 50,000 points,
     # DEFAULT arguments -- adaptive dopri5 for sampling (cell 388), dopri5 + exact trace for log_prob (cell 467)
     torch.manual_seed(0)
@@ -249,6 +286,18 @@ def extra_configs(device):
         entry[f"sample_ms_{prec}"] = 1e3 * min(_timed(lambda: nb.sample_ode_from_base(zb), device)[1] for _ in range(3))
         entry[f"sample_attempts_{prec}"] = dict(nb.last_solver_stats)
         entry[f"log_prob_ms_{prec}"] = 1e3 * min(_timed(lambda: nb.log_prob(xb), device)[1] for _ in range(3))
+        entry[f"log_prob_attempts_{prec}"] = dict(nb.last_solver_stats)
+    # round 2's host-side step controller on the same calls (FF_HOST_CONTROLLER=1), for the record
+    nb.precision = "f32"
+    os.environ["FF_HOST_CONTROLLER"] = "1"
+    try:
+        nb.sample_ode_from_base(zb[:512].contiguous())
+        nb.log_prob(xb[:512].contiguous())
+        entry["sample_ms_f32_host_controller"] = 1e3 * min(_timed(lambda: nb.sample_ode_from_base(zb), device)[1] for _ in range(3))
+        entry["sample_attempts_f32_host_controller"] = dict(nb.last_solver_stats)
+        entry["log_prob_ms_f32_host_controller"] = 1e3 * min(_timed(lambda: nb.log_prob(xb), device)[1] for _ in range(3))
+    finally:
+        os.environ.pop("FF_HOST_CONTROLLER", None)
     out.append(entry)
     del nb, zb, xb
     # --- config 4: 64-dim flow matching, 5x512, 200 fixed Dormand-Prince steps, 2^22 / 8 GPUs = 2^19 per GPU ------
@@ -297,6 +346,94 @@ def extra_configs(device):
                                  "note": "executed bf16 MFMA work (three products per term, padding of the 40-feature first layer not "
                                          "counted) vs the dense bf16 peak"}})
     return out
+
+
+def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_steps=200, em_steps=1000):
+    """N > 1: the two BASELINE configurations worded for a node, sharded `world` ways, one all-gather each.
+    configs[3]: 64-dim flow 5x512, `flow_steps`-step fixed Dormand-Prince, `rows_c4` rows over the node; base samples from
+    the library's counter-based stream keyed by the GLOBAL row, so every world size transports the same points.
+    configs[4]: conditional 32-dim VE 4x256 (8 conditionals), `em_steps`-step Euler-Maruyama, `rows_c5` rows; prior,
+    per-step noise and the conditionals keyed by the global row (distributed.sample_sde_sharded).
+    Every rank reports its kernel ms (HIP events around its solve) and gather ms; rank-invariance: the rank's first 256
+    rows equal a single-launch solve of those rows, bit for bit."""
+    from flowfusion_amd import _native
+    from flowfusion_amd import flow as Fm
+    from flowfusion_amd.diffusion import MLP, VESDE, ScoreModel
+    from flowfusion_amd.distributed import gather_rows, sample_sde_sharded, shard_bounds
+    gather_dev = device if backend == "nccl" else torch.device("cpu")
+    recs, invariant = [], True
+
+    def timed_gather(local, n_total):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        full = gather_rows(local if backend == "nccl" else local.cpu(), n_total)
+        if backend == "nccl":
+            torch.cuda.synchronize(device)
+        return full, 1e3 * (time.perf_counter() - t0)
+
+    def per_rank(values):
+        mine = torch.tensor(values, device=gather_dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        return [[float(t[i]) for t in allr] for i in range(len(values))]
+
+    # --- configs[3] ---------------------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    f = Fm.ODEFlow(64, [512] * 5).to(device).eval()
+    lo, hi = shard_bounds(rows_c4, world, rank)
+    xT = _native.normal_fill(hi - lo, 64, 2024, lo, device)
+    o4 = {"step_size": 1.0 / flow_steps}
+    f.sample(xT[:64].contiguous(), method="dopri5_fixed", options=o4)
+    dist.barrier()
+    y, wall, kms = _timed(lambda: f.sample(xT, method="dopri5_fixed", options=o4), device)
+    full, gms = timed_gather(y, rows_c4)
+    head = f.sample(xT[:256].contiguous(), method="dopri5_fixed", options=o4)
+    ok4 = bool(torch.equal(head, y[:256])) and bool(torch.equal(full[lo:lo + 256].to(device), y[:256]))
+    invariant &= ok4
+    walls, kmss, gmss = per_rank([1e3 * wall, kms, gms])
+    mac4 = 65 * 512 + 4 * 512 * 512 + 512 * 64
+    n_evals4 = 6 * flow_steps
+    slow = max(w + g for w, g in zip(walls, gmss)) * 1e-3
+    recs.append({"workload": f"BASELINE configs[3]: 64-dim flow matching 5x512, {flow_steps}-step fixed Dormand-Prince "
+                             f"({n_evals4} evals), {rows_c4} rows sharded over {world} GPUs, one all-gather",
+                 "value": rows_c4 / slow, "unit": "samples/s", "rows_per_rank": hi - lo, "kernel": _native.kernel_name(f._net().plan(0)),
+                 "per_rank": {"wall_ms": walls, "kernel_ms": kmss, "allgather_ms": gmss}, "dtype": "f32",
+                 "roofline": {"bound": "mfma", "achieved": 2.0 * mac4 * n_evals4 * (hi - lo) / (kms * 1e-3) / 1e12,
+                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": 2.0 * mac4 * n_evals4 * (hi - lo) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                              "note": "rank 0's launch"}, "rank_invariant": ok4})
+    del f, xT, y, full, head
+    # --- configs[4] ---------------------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    sm5 = ScoreModel(MLP(32, 8, EMB, UNITS), VESDE()).eval().to(device)
+    lo, hi = shard_bounds(rows_c5, world, rank)
+    cond = _native.normal_fill(hi - lo, 8, 77, lo, device)            # conditionals keyed by the global row as well
+    sample_sde_sharded(sm5, (rows_c5, 32), steps=8, seed=1, gather=False, local_conditional=cond)
+    dist.barrier()
+    (y, _), wall, kms = _timed(lambda: sample_sde_sharded(sm5, (rows_c5, 32), steps=em_steps, seed=1, gather=False,
+                                                           local_conditional=cond), device)
+    full, gms = timed_gather(y, rows_c5)
+    # the same rows as a launch of their own: prior, noise and conditionals are functions of the global row
+    scale = float(sm5.sde.sigma_max)
+    x256 = _native.normal_fill(min(256, hi - lo), 32, 1, lo, device, scale=scale)
+    head = sm5._sample_sde_from(x256, None, cond[:256].contiguous(), em_steps, rng=(1, lo))
+    ok5 = bool(torch.equal(head, y[:256])) and bool(torch.equal(full[lo:lo + 256].to(device), y[:256]))
+    invariant &= ok5
+    walls, kmss, gmss = per_rank([1e3 * wall, kms, gms])
+    mac5 = mac_per_eval(32, UNITS, 8)
+    slow = max(w + g for w, g in zip(walls, gmss)) * 1e-3
+    recs.append({"workload": f"BASELINE configs[4]: conditional 32-dim VE-SDE 4x256 (8 conditionals), {em_steps}-step "
+                             f"Euler-Maruyama, {rows_c5} rows sharded over {world} GPUs, in-kernel noise keyed by the global row, "
+                             "one all-gather", "value": rows_c5 / slow, "unit": "samples/s", "rows_per_rank": hi - lo,
+                 "kernel": _native.kernel_name(sm5._net().plan(0)),
+                 "per_rank": {"wall_ms": walls, "kernel_ms": kmss, "allgather_ms": gmss}, "dtype": "f32",
+                 "roofline": {"bound": "mfma", "achieved": 2.0 * mac5 * em_steps * (hi - lo) / (kms * 1e-3) / 1e12,
+                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": 2.0 * mac5 * em_steps * (hi - lo) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                              "note": "rank 0's launch (prior draw included in kernel_ms)"}, "rank_invariant": ok5})
+    flag = torch.tensor([1.0 if invariant else 0.0], device=gather_dev, dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return recs, bool(flag.item() == 1.0)
 
 
 def streaming_helpers(device):
@@ -354,6 +491,10 @@ def main():
                     help="skip the one-launch timings of BASELINE configs 3, 4, 5 (N = 1 only)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--c4-rows", type=int, default=1 << 22, help="N > 1: rows of BASELINE configs[3] over the node")
+    ap.add_argument("--c5-rows", type=int, default=1 << 20, help="N > 1: rows of BASELINE configs[4] over the node")
+    ap.add_argument("--c4-steps", type=int, default=200, help="N > 1: fixed steps of configs[3] (rehearsals shorten it)")
+    ap.add_argument("--c5-steps", type=int, default=1000, help="N > 1: Euler-Maruyama steps of configs[4]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -378,12 +519,17 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    # host threads: the ranks of a node share its cores (table building, packing, the gloo rehearsal's copies)
+    host_threads = max(1, usable_cores() // world)
+    torch.set_num_threads(host_threads)
     sm = build_model(device)
     eps = float(sm.sde.epsilon)
     opts = {"step_size": (1.0 - eps) / N_STEPS}
     B = args.batch
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    z = torch.randn(B, DIM, device=device, generator=gen)
+    # base samples from the library's counter-based stream keyed by the GLOBAL row (rank r holds rows [r B, (r + 1) B)):
+    # a row's sample does not depend on how many ranks there are
+    from flowfusion_amd import _native
+    z = _native.normal_fill(B, DIM, 1234, rank * B, device)
     gather_dev = device if args.backend == "nccl" else torch.device("cpu")
     gathered = torch.empty(world * B, DIM, device=gather_dev) if world > 1 else None
 
@@ -411,7 +557,6 @@ def main():
     barrier()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     net = sm._net()
-    from flowfusion_amd import _native
     kernel_name = _native.lib().ff_kernel_name(net.plan(0).kernel_id).decode()
     table = sm._ode_table(torch.tensor([1.0, eps]), "rk4", opts, 0).to(device)
     n_evals = table.shape[0]
@@ -437,6 +582,20 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"kernel_ms_avg": [float(t[0]) for t in allr], "allgather_ms_avg": [float(t[1]) for t in allr]}
+    # rank invariance of the headline: this rank's first 256 rows as a launch of their own, and as they arrived in the
+    # gathered tensor, equal the rows of the timed solve bit for bit
+    head, _ = sm.sample_ode_from_base(z[:256].contiguous(), method="rk4", options=opts)
+    rank_invariant = bool(torch.equal(head, x[:256]))
+    sharded = None
+    if world > 1:
+        rank_invariant &= bool(torch.equal(gathered[rank * B: rank * B + 256].to(device), x[:256]))
+        if args.extras:
+            sharded, ok = sharded_extras(device, world, rank, dist, args.backend, args.c4_rows, args.c5_rows,
+                                         args.c4_steps, args.c5_steps)
+            rank_invariant &= ok
+        flag = torch.tensor([1.0 if rank_invariant else 0.0], device=gather_dev, dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rank_invariant = bool(flag.item() == 1.0)
 
     if rank == 0:
         print(f"[bench] timed region {elapsed:.3f} s, kernel avg {kernel_ms_avg:.1f} ms", file=sys.stderr, flush=True)
@@ -469,8 +628,12 @@ def main():
                          "algorithmic_hbm_GBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9,
                          "hbm_frac_of_8TBps": alg_bytes / (kernel_ms_avg * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        out["rank_invariant"] = rank_invariant
+        out["host_threads_per_rank"] = host_threads
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if sharded is not None:
+            out["extra_configs"] = sharded
         # `traffic` cannot be measured by this process (PMC counters need a rocprofv3 pass of their own): it is the
         # committed result of tools/profile_round.sh for this kernel at this batch, and says so
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
@@ -489,8 +652,10 @@ def main():
             xg, _ = sm.sample_ode_from_base(zc.to(device), method="rk4", options=opts)
             out["parity_vs_cpu_oracle"] = {
                 "max_abs_err_over_max_abs": float((xg.cpu() - ref).abs().max() / ref.abs().max()),
-                "n": int(zc.shape[0])}
-            # log_prob relative error (second half of BASELINE's metric), Hutchinson, 100-step RK4
+                "n": int(zc.shape[0]), "kernel": _native.kernel_name(sm._net().plan(0))}
+            # log_prob relative error (second half of BASELINE's metric), Hutchinson, 100-step RK4.  Every accuracy figure
+            # of this line names the kernel that produced it and says how many of its output elements differ from the f32
+            # kernel's: identical maxima of different arithmetics are then visibly not the same numbers served three times.
             from oracle import flowfusion_oracle as O
             sd = {k: v.detach().cpu() for k, v in sm.state_dict().items()}
             so = O.ScoreOracle(O.mlp_params_from_state_dict(sd, "model."), O.VP(), no_sigma=True)
@@ -499,7 +664,10 @@ def main():
             xq = torch.randn(128, DIM) * 0.9
             lp = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
             lp_ref = so.log_prob(xq, None, "rk4", opts, "hutch", sm.e.cpu())
-            out["log_prob_rel_err"] = float(((lp - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+            rel = lambda got: ((got - lp_ref).abs() / lp_ref.abs().clamp_min(1.0))
+            out["log_prob_rel_err"] = float(rel(lp).max())
+            out["log_prob_evidence"] = {"kernel": _native.kernel_name(sm._net().plan(1)), "n": int(lp.numel()),
+                                        "argmax": int(rel(lp).argmax())}
             split_lp_err = {}
             if args.extras:     # the same check on the split-precision kernels (same points, same probe)
                 for prec in ("bf16x3", "bf16x2"):
@@ -507,32 +675,46 @@ def main():
                     torch.manual_seed(99)
                     assert torch.equal(torch.randn(128, DIM) * 0.9, xq)
                     lps = sm.log_prob(xq.to(device), method="rk4", options=opts).cpu()
-                    split_lp_err[prec] = float(((lps - lp_ref).abs() / lp_ref.abs().clamp_min(1.0)).max())
+                    split_lp_err[prec] = {"log_prob_rel_err": float(rel(lps).max()),
+                                          "log_prob_evidence": {
+                                              "kernel": _native.kernel_name(sm._net().plan(1)), "n": int(lps.numel()),
+                                              "argmax": int(rel(lps).argmax()),
+                                              "n_elements_differing_from_f32_result": int((lps != lp).sum()),
+                                              "max_abs_diff_vs_f32_result": float((lps - lp).abs().max())}}
                 sm.precision = "f32"
             sm.hutch = False
             _, _, cb1 = cpu_baseline(sm, 2048, opts, budget_s=10.0, threads=1)
             out["cpu_baseline_1thread"] = cb1
-            torch.set_num_threads(usable_cores())
+            torch.set_num_threads(host_threads)
         if args.extras and world == 1:
             out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x3")
             out["split_precision_record_bf16x2"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x2")
             if args.cpu_batch > 0:
-                out["split_precision_record"]["log_prob_rel_err"] = split_lp_err["bf16x3"]
-                out["split_precision_record_bf16x2"]["log_prob_rel_err"] = split_lp_err["bf16x2"]
+                out["split_precision_record"].update(split_lp_err["bf16x3"])
+                out["split_precision_record_bf16x2"].update(split_lp_err["bf16x2"])
                 # state error of each arithmetic against the float64 oracle on the CPU sample's base points
                 from oracle import flowfusion_oracle as O64
                 so64 = O64.ScoreOracle(O64.mlp_params_from_state_dict(sd, "model."), O64.VP(dtype=torch.float64), no_sigma=True,
                                        dtype=torch.float64)
                 zs = zc[:256]
                 r64 = so64.sample_ode_from_base(zs.double(), None, "rk4", opts)
+                x_f32 = None
                 for prec, key in (("f32", None), ("bf16x3", "split_precision_record"), ("bf16x2", "split_precision_record_bf16x2")):
                     sm.precision = prec
                     xg, _ = sm.sample_ode_from_base(zs.to(device), method="rk4", options=opts)
-                    e64 = float((xg.cpu().double() - r64).abs().max() / r64.abs().max())
+                    xg = xg.cpu()
+                    err = (xg.double() - r64).abs()
+                    e64 = float(err.max() / r64.abs().max())
+                    ev = {"kernel": _native.kernel_name(sm._net().plan(0)), "n": int(xg.numel()), "argmax": int(err.argmax())}
                     if key is None:
+                        x_f32 = xg
                         out["parity_vs_cpu_oracle"]["max_abs_err_over_max_abs_vs_float64_oracle"] = e64
+                        out["parity_vs_cpu_oracle"]["float64_oracle_evidence"] = ev
                     else:
+                        ev["n_elements_differing_from_f32_result"] = int((xg != x_f32).sum())
+                        ev["max_abs_diff_vs_f32_result"] = float((xg - x_f32).abs().max())
                         out[key]["max_abs_err_over_max_abs_vs_float64_oracle"] = e64
+                        out[key]["float64_oracle_evidence"] = ev
                 sm.precision = "f32"
             out["extra_configs"] = extra_configs(device)
             out["streaming_helpers"] = streaming_helpers(device)

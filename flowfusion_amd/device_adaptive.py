@@ -27,6 +27,8 @@ from . import _native, adaptive
 from ._native import MODE_EXACT, MODE_STATE
 
 FIRST_CHUNK = 16          # attempted steps enqueued before the first look at the state
+TRACE = None              # diagnostics: a list collects (attempts, accepted, t, dt, last error ratio) after every attempted step
+                          # (one attempt per chunk while it is set; scratch/diag_adaptive_pair.py)
 MAX_CHUNK = 64
 MAX_TIME_COLS = 64        # kMaxTimeCols of ff_adaptive.hip
 
@@ -169,7 +171,7 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
     if probe_d is not None and tuple(probe_d.shape) != (B, D):
         raise RuntimeError(f"probe has shape {tuple(probe_d.shape)}, expected {(B, D)}")
     L = _native.lib()
-    first_chunk = int(os.environ.get("FF_ADAPT_CHUNK", FIRST_CHUNK))
+    first_chunk = 1 if TRACE is not None else int(os.environ.get("FF_ADAPT_CHUNK", FIRST_CHUNK))
     what, n, chunks = _native.ADAPT_START | _native.ADAPT_FINISH, first_chunk, 0
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -191,12 +193,14 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
                 err = RuntimeError(msg)
                 err.solver_stats = {"attempts": int(st.n_attempts), "accepted": int(st.n_accepted), "chunks": chunks}
                 raise err
+            if TRACE is not None:
+                TRACE.append((int(st.n_attempts), int(st.n_accepted), float(st.t), float(st.dt), float(st.last_ratio)))
             if st.done:
                 break
             if not st.active:
                 raise RuntimeError("adaptive controller stopped without finishing")       # cannot happen
             left = (st.t_end - st.t) / st.dt if st.dt > 0 else MAX_CHUNK
-            n = int(min(MAX_CHUNK, max(4, math.ceil(left * 1.3) + 2)))
+            n = 1 if TRACE is not None else int(min(MAX_CHUNK, max(4, math.ceil(left * 1.3) + 2)))
             what = _native.ADAPT_FINISH
     del keep
     stats = {"attempts": int(st.n_attempts), "accepted": int(st.n_accepted), "chunks": chunks}

@@ -66,12 +66,13 @@ def run_sharded(fn: Callable[..., torch.Tensor], inputs: Sequence[Optional[torch
 
 
 def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] = None, steps: int = 100,
-                       seed: int = 0, group=None, gather: bool = True):
+                       seed: int = 0, group=None, gather: bool = True, local_conditional: Optional[torch.Tensor] = None):
     """Euler-Maruyama sampling (``ScoreModel.sample_sde``) of a [B, dim] batch over all ranks, with the
     same result for any number of ranks: both the prior draw and the per-step noise come from the library's
     counter-based stream keyed by ``seed`` and the GLOBAL row index (prior: ``ff_normal_fill`` with the reserved
     noise index; steps: ``noise="philox"``), so a rank only ever touches its own rows.  One all-gather at the
-    end."""
+    end.  ``conditional`` is the full [B, C] tensor (every rank slices its rows); ``local_conditional`` is this rank's
+    [hi - lo, C] rows already (a consumer that never materialises the full batch)."""
     from . import _native
     batch, *dims = shape
     if len(dims) != 1:
@@ -85,6 +86,10 @@ def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] =
     scale = float(sde.sigma_max) if hasattr(sde, "sigma_max") else 1.0
     x = _native.normal_fill(hi - lo, dims[0], int(seed), lo, dev, scale=scale)
     cond = None if conditional is None else conditional[lo:hi].contiguous()
+    if local_conditional is not None:
+        if conditional is not None or local_conditional.shape[0] != hi - lo:
+            raise ValueError("local_conditional must hold exactly this rank's rows (and excludes `conditional`)")
+        cond = local_conditional.contiguous()
     local = score_model._sample_sde_from(x, None, cond, steps, rng=(int(seed), lo))
     if not gather:
         return local, (lo, hi)

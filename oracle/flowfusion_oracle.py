@@ -513,7 +513,10 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
         sum(k[j] * (coefs[i] * scale) for i, k in enumerate(ks)) for j in range(len(y0)))
     t0 = t[0]
     f0 = func(t0.to(dty), y0)
-    # initial step (order - 1 = 4 is what the solver passes)
+    # initial step (order - 1 = 4 is what the solver passes); options["first_step"] replaces the rule (torchdiffeq
+    # RKAdaptiveStepsizeODESolver._before_integrate)
+    first_step = opts.get("first_step")
+    max_num_steps = int(opts.get("max_num_steps", 2 ** 31 - 1))
     scale = tuple(atol + a.abs() * rtol for a in y0)
     d0 = _tuple_norm([a / s for a, s in zip(y0, scale)])
     d1 = _tuple_norm([a / s for a, s in zip(f0, scale)])
@@ -527,12 +530,17 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     else:
         h1 = (0.01 / max(d1, d2)) ** (1.0 / order)
     dt = torch.min(100 * h0, h1.abs()).double()
+    if first_step is not None:
+        dt = torch.as_tensor(float(first_step), dtype=torch.float64)
 
     y, f = tuple(y0), f0
     t_lo = t_hi = t0
     last = None
     last_adaptive_stats.update(attempts=0, accepted=0)
+    n_steps = 0
     while t[-1] > t_hi:
+        assert n_steps < max_num_steps, f"max_num_steps exceeded ({n_steps}>={max_num_steps})"
+        n_steps += 1
         dt = dt.clamp(min_step, max_step)                         # every attempt starts from a clamped step
         ta, tb = t_hi, t_hi + dt
         if not bool(ta + dt > ta):

@@ -46,16 +46,18 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [64, 37])          # even and ragged shards
-def test_world_size_2_gloo(n):
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 37), (8, 64), (8, 37), (8, 5)])     # even, ragged, fewer rows than ranks
+def test_sharding_and_gather_over_gloo(world, n):
+    """world 2 and world 8 (the node the north star names): bench.py's N > 1 branch and distributed.py reduce to
+    `shard_bounds` + one all-gather, whatever the world size."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    results = dict(q.get(timeout=5) for _ in range(2))
-    assert results == {0: True, 1: True}
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}

@@ -388,8 +388,12 @@ def test_split_exact_trace(name, prec, built_library):
     stats = dict(sm.last_solver_stats)
     sm.precision = "f32"
     lp32 = sm.log_prob(x0[:40].to(DEV), conditional=None if cd is None else cd[:40])
-    # the same controller on fp32-class right-hand sides: the same steps, give or take an attempt whose error ratio sat at 1
-    assert abs(sm.last_solver_stats["attempts"] - stats["attempts"]) <= 2 and _logp_err(lpd, lp32.cpu()) < 2e-4
+    # The same controller on fp32-class right-hand sides walks a similar step sequence -- not the same one: the error ratio
+    # feeds back into the step size (err ~ dt^5), so a 1e-7 difference in the right-hand side grows to percents of the ratio
+    # within ten steps and sooner or later flips an accept (scratch/diag_adaptive_pair.py prints such a pair attempt by
+    # attempt).  Two solves at the default rtol = atol = 1e-4 then differ by what the tolerances allow per accepted step,
+    # (1e-4 + 1e-4 |lp|) x ~10 steps; measured between f32 / bf16x2 / bf16x3 and the two controllers: 2e-5 .. 2.7e-4.
+    assert abs(sm.last_solver_stats["attempts"] - stats["attempts"]) <= 3 and _logp_err(lpd, lp32.cpu()) < 5e-4
 
 
 @pytest.mark.gpu
@@ -600,7 +604,9 @@ def test_split_random_shapes_against_oracle(built_library):
             xd = torch.randn(B, Dm) * 0.5
             lp = sm.log_prob(xd.to(DEV), conditional=cd, method=method, options=opts)
             e = sm.e.cpu().double() if sm.hutch else None
-            assert _logp_err(lp, so64.log_prob(xd.double(), c64, method, opts, mode, e).float()) < LOGP_TOL, tag + (mode,)
+            # (two-part operands carry 16 significand bits: twice the fp32 kernels' bar, a fifth of north_star's 1e-4)
+            tol = LOGP_TOL * (2 if prec == "bf16x2" else 1)
+            assert _logp_err(lp, so64.log_prob(xd.double(), c64, method, opts, mode, e).float()) < tol, tag + (mode,)
             kernels.add(_native.kernel_name(sm._net().plan(1 if sm.hutch else 2)))
             sm.hutch = False
         if case % 4 == 0:

@@ -1,6 +1,6 @@
 """Shrink a rocprofv3 output directory in place (run on the GPU box after each pass): keep the per-kernel statistics
-whole, keep only the fused kernels' rows of the per-dispatch CSVs (the Euler-Maruyama workload alone launches
-thousands of torch random-number kernels), drop everything else.  usage: filter_rocprof.py DIR"""
+whole, keep only the library's kernels' rows (namespace ff::) of the per-dispatch CSVs (the Euler-Maruyama workload alone
+launches thousands of torch random-number kernels), drop everything else.  usage: filter_rocprof.py DIR"""
 import csv
 import sys
 from pathlib import Path
@@ -16,7 +16,7 @@ for f in list(root.rglob("*")):
             r = csv.reader(g)
             head = next(r)
             k = head.index("Kernel_Name")
-            rows = [row for row in r if "mlp_ode" in row[k]]
+            rows = [row for row in r if "ff::" in row[k]]
         with open(f, "w", newline="") as g:
             w = csv.writer(g)
             w.writerow(head)

@@ -4,7 +4,12 @@
 
 * bench_1gpu.json, bench_under_rocprof.json     the bench lines (headline, split-precision record, extra_configs)
 * kernel_stats.csv, kernel_trace_mlp_ode.csv    rocprofv3 --kernel-trace --stats of the same command (names trimmed);
-                                                the trace lists every launch of the fused kernels with its duration
+                                                the trace lists every launch of the library's kernels with its duration,
+                                                each dispatch ONCE (rocprofv3 repeats rows when a run writes several
+                                                per-process files)
+* kernel_durations_by_grid.csv                  launches grouped by (kernel, grid size): calls, mean / min / max / sigma
+                                                in ms -- kernel_stats.csv averages over every batch size a kernel ran
+                                                at; the dominant launch's average is one row of THIS table
 * pmc_summary.json  and  ../hbm_traffic.json    PMC counters per fused kernel, per launch (the LARGEST launch of each
                                                 kernel = the full-size timed one), with the gfx950 corrections of
                                                 MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request -> doubled;
@@ -50,20 +55,38 @@ def main(src: Path, dst: Path):
             w.writerow(row)
     trace = find(src / "trace", "kernel_trace.csv")
     durations = {}
+    by_grid = {}
+    seen = set()
     with open(trace) as f, open(dst / "kernel_trace_mlp_ode.csv", "w", newline="") as g:
         r = csv.DictReader(f)
-        keep = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Workgroup_Size", "Grid_Size", "LDS_Block_Size",
-                "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"]
+        keep = ["Kernel_Name", "Start_Timestamp", "End_Timestamp", "Workgroup_Size", "Workgroup_Size_X", "Grid_Size", "Grid_Size_X",
+                "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count"]
         keep = [k for k in keep if k in r.fieldnames]
+        grid_col = "Grid_Size_X" if "Grid_Size_X" in r.fieldnames else ("Grid_Size" if "Grid_Size" in r.fieldnames else None)
         w = csv.DictWriter(g, fieldnames=keep + ["Duration_ns"])
         w.writeheader()
         for row in r:
+            if "ff::" not in row["Kernel_Name"]:
+                continue
+            key = (row["Kernel_Name"], row["Start_Timestamp"], row["End_Timestamp"])
+            if key in seen:                 # the same dispatch listed twice
+                continue
+            seen.add(key)
+            out = {k: row[k] for k in keep}
+            out["Duration_ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            out["Kernel_Name"] = trim(out["Kernel_Name"])
+            durations.setdefault(row["Kernel_Name"], []).append(out["Duration_ns"])
+            by_grid.setdefault((trim(row["Kernel_Name"]), row[grid_col] if grid_col else "?"), []).append(out["Duration_ns"])
             if "mlp_ode" in row["Kernel_Name"]:
-                out = {k: row[k] for k in keep}
-                out["Duration_ns"] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-                out["Kernel_Name"] = trim(out["Kernel_Name"])
-                durations.setdefault(row["Kernel_Name"], []).append(out["Duration_ns"])
                 w.writerow(out)
+    with open(dst / "kernel_durations_by_grid.csv", "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(["Kernel_Name", "Grid_Size_X", "Calls", "Mean_ms", "Min_ms", "Max_ms", "Stddev_ms", "Total_ms"])
+        for (name, grid), ds in sorted(by_grid.items(), key=lambda kv: -sum(kv[1])):
+            n = len(ds)
+            mean = sum(ds) / n
+            sd = (sum((d - mean) ** 2 for d in ds) / n) ** 0.5
+            w.writerow([name, grid, n] + [f"{v / 1e6:.4f}" for v in (mean, min(ds), max(ds), sd, sum(ds))])
 
     counters = {}          # kernel -> counter -> [values over dispatches]
     i = 0
