@@ -241,9 +241,9 @@ def make_plan(dim: int, cond_dim: int, hidden: List[int], mode: int,
         raise NotImplementedError(
             f"precision='{name}' (one of the split-precision options 'bf16x3' / 'bf16x2') has no kernel for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "
             f"activation={act[0]}: the split-precision family covers SiLU networks of 1-4 hidden layers up to 256 wide, "
-            "cond_dim <= 16, dim <= 16 in every mode (state-only, Euler-Maruyama included, Hutchinson and exact-trace solves; "
-            "fixed grids and the adaptive methods) and, bf16x2 only, dim <= 32 for state-only solves with at most 4 "
-            "Runge-Kutta stages; use precision='f32'")
+            "cond_dim <= 16, dim <= 16: bf16x3 state-only solves (sampling, Euler-Maruyama; fixed grids and the adaptive "
+            "methods); bf16x2 also Hutchinson and exact-trace log-densities and, state-only with at most 4 Runge-Kutta "
+            "stages, dim <= 32; use precision='f32'")
     if rc == FF_ERR_UNSUPPORTED:
         raise NotImplementedError(
             f"no gfx950 kernel instantiation for dim={dim}, cond_dim={cond_dim}, hidden={hidden}, mode={mode}, "

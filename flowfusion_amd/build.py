@@ -18,10 +18,12 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
-GEN = PKG / "_build" / "gen"
-OBJ = PKG / "_build" / "obj"
+# FF_BUILD_FULL=1 (round 2's instance set, for A/B measurements) builds beside the product library, not over it
+FULL = os.environ.get("FF_BUILD_FULL", "") not in ("", "0")
+GEN = PKG / "_build" / ("gen_full" if FULL else "gen")
+OBJ = PKG / "_build" / ("obj_full" if FULL else "obj")
 LIBDIR = PKG / "lib"
-LIB = LIBDIR / "libflowfusion_amd.so"
+LIB = LIBDIR / ("libflowfusion_amd_full.so" if FULL else "libflowfusion_amd.so")
 
 ARCH = "gfx950"
 
@@ -37,15 +39,18 @@ ARCH = "gfx950"
 # reference demo shape or a documented option of the reference's constructors reaches.
 # FF_BUILD_FULL=1 restores the round-2 set (compiled-in activations, 5-6 hidden layers on the split family, ...) for
 # A/B measurements.
-FULL = os.environ.get("FF_BUILD_FULL", "") not in ("", "0")
-
 INSTANCES = [
-    # narrow networks: 32 samples per wavefront, one wavefront per SIMD
+    # narrow networks: 32 samples per wavefront, one wavefront per SIMD (width 64; width 128 beyond 16 dimensions)
     (32, h, d, c, t, 1, 8, 0)
-    for h in (64, 128)
-    for d in (4, 8, 16)
+    for (h, ds) in ((64, (4, 8, 16)), (128, (16,)))
+    for d in ds
     for c in (0, 8)
     for t in (0, 1)
+] + [
+    # 128-wide networks on the 16-column tile, two wavefronts per SIMD (round 3: the reference's own notebook networks are
+    # 3x128; the 32-column kernels ran them at ~65 % of the MFMA rate with one wavefront per SIMD -- measured
+    # scratch/tile16_h128.py: +8..12 % at 2^20 samples, notebook log_prob 19.1 -> 16.7 ms)
+    (16, 128, 4, c, t, 2, 8, 0) for c in (0, 4) for t in (0, 1)
 ] + [
     # Two wavefronts per SIMD: with 16 samples per wavefront a 256-wide network needs only 64 + 64
     # activation/accumulator registers, so two wavefronts share a SIMD and one's VALU work (SiLU,
@@ -65,23 +70,31 @@ INSTANCES = [
     # samples fill the register file of one wavefront per SIMD
     (16, 512, 16, 4, t, 1, 4, 0) for t in (0, 1)
 ] + [
-    # non-default activations (`activation=` of the reference constructors): ONE instantiation per width and mode that
-    # chooses the function at run time (ACT = 9; the chosen kind's stages run back to back behind a wave-uniform switch).
-    # The divergence-capable 256-wide one runs one wavefront per SIMD: with the switch at every activation site two
-    # wavefronts per SIMD spill 187 registers.
-    (32, 128, 16, 8, 0, 1, 8, 9), (32, 128, 16, 8, 1, 1, 8, 9),
-    (16, 256, 8, 4, 0, 2, 8, 9), (16, 256, 8, 4, 1, 1, 8, 9),
-    (16, 512, 16, 4, 0, 1, 4, 9), (16, 512, 16, 4, 1, 1, 4, 9),
+    # Non-default activations (`activation=` of the reference constructors; its code, docs and notebooks only ever use
+    # SiLU).  ACT = 9 chooses the function at run time (the chosen kind's stages run back to back behind a wave-uniform
+    # switch): measured against the compiled-in variants (scratch/act_bench.py, profiles/r03/act_bench.txt) it costs
+    # 0-3 % for state-only solves at width 256 and is what the 512-wide kernels (a minute of compile time each) use;
+    # with tangent columns at width 256 it costs 16 % (the switch at every activation site spills 187 registers at two
+    # wavefronts per SIMD, so it runs one) and 9-11 % at width 128: those keep a compiled-in instantiation per
+    # activation (ACT = 1..8), without cooperative twins.
+    (16, 256, 8, 4, 0, 2, 8, 9), (16, 512, 16, 4, 0, 1, 4, 9), (16, 512, 16, 4, 1, 1, 4, 9),
+] + [
+    (tile, h, d, c, t, wps, 8, act)
+    for act in range(1, 9)
+    for (tile, h, d, c, t, wps) in ((32, 128, 16, 8, 0, 1), (32, 128, 16, 8, 1, 1), (16, 256, 8, 4, 1, 2))
 ] + ([
     # round-2 extras (FF_BUILD_FULL): width 256 on the 32-wide tile (A/B runs, FF_TILE=32); up to 32 conditional inputs
-    # at width 512 (the wide catch-alls serve them otherwise); every non-SiLU activation compiled in per width <= 256
+    # at width 512 (the wide catch-alls serve them otherwise); the narrow 32-column shapes the 16-column tile replaced;
+    # every non-SiLU activation compiled in per width <= 256 and mode, and run-time choice everywhere
     (32, 256, 8, 0, 0, 1, 8, 0), (32, 256, 8, 0, 1, 1, 8, 0),
     (16, 512, 16, 8, 0, 1, 4, 0), (16, 512, 16, 8, 1, 1, 4, 0),
+    (32, 128, 16, 8, 0, 1, 8, 9), (32, 128, 16, 8, 1, 1, 8, 9), (16, 256, 8, 4, 1, 1, 8, 9),
 ] + [
-    (tile, h, d, c, t, wps, ring, act)
+    (32, 128, d, c, t, 1, 8, 0) for d in (4, 8) for c in (0, 8) for t in (0, 1)
+] + [
+    (tile, h, d, c, t, wps, 8, act)
     for act in range(1, 9)
-    for (tile, h, d, c, wps, ring) in ((32, 64, 16, 8, 1, 8), (32, 128, 16, 8, 1, 8), (16, 256, 8, 4, 2, 8))
-    for t in (0, 1)
+    for (tile, h, d, c, t, wps) in ((32, 64, 16, 8, 0, 1), (32, 64, 16, 8, 1, 1), (16, 256, 8, 4, 0, 2))
 ] if FULL else [])
 
 # Wide catch-alls (kernel template WIDE: cooperative at every batch size, hidden operands read from LDS): networks up
@@ -97,14 +110,17 @@ def _wide_name(tile, h, d, c, t) -> str:
 # 2 = FF_PREC_BF16X2, 16-dimension tiles of the state: 1 = dim <= 16; 2 = dim <= 32 (two-part kernels only), on-chip
 # width: 256, or 128 for networks up to 128 wide).  TANGENTS: 0 state only, 1 Hutchinson column pairs, 2 exact trace.
 # Frozen in round 3 at what the BASELINE configurations and the reference's demo networks reach: 1-4 hidden layers
-# (configs 2, 3 and 5 are 4x256, the notebooks 3x128), every mode for states of up to 16 dimensions, state-only
-# (Euler-Maruyama: config 5) for 17-32 dimensions, 128-wide instances for the two-part option only.
+# (configs 2, 3 and 5 are 4x256, the notebooks 3x128); two parts: every mode for states of up to 16 dimensions, state-only
+# (Euler-Maruyama: config 5) for 17-32 dimensions, 128-wide instances; three parts: state-only, 256 wide.
 if FULL:
     SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
                       [(nh, t, 2, 2, 256) for nh in (1, 2, 3, 4, 5, 6) for t in (0, 1, 2)] + \
                       [(nh, t, parts, dt, 128) for (parts, dt) in ((3, 1), (2, 1), (2, 2)) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 else:
-    SPLIT_INSTANCES = [(nh, t, parts, 1, 256) for parts in (3, 2) for nh in (1, 2, 3, 4) for t in (0, 1, 2)] + \
+    # three parts (fp32-class): the state-only kernels -- the second record of the headline workload is what round 1 asked
+    # of this option; log-densities under precision= take the two-part kernels or f32
+    SPLIT_INSTANCES = [(nh, 0, 3, 1, 256) for nh in (1, 2, 3, 4)] + \
+                      [(nh, t, 2, 1, 256) for nh in (1, 2, 3, 4) for t in (0, 1, 2)] + \
                       [(nh, 0, 2, 2, 256) for nh in (1, 2, 3, 4)] + \
                       [(nh, t, 2, 1, 128) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 
@@ -120,8 +136,8 @@ def _split_name(nh, t, parts=3, dt=1, width=256) -> str:
 
 def _has_coop(h, act=0) -> bool:
     """Instances that get a cooperative twin: the blocks of a layer (H / 32) must split four ways.  (Of the
-    non-SiLU activations only the 128- and 256-wide shapes get one: build time.)"""
-    return (h // 32) % 4 == 0 and (act == 0 or h <= 256)
+    non-SiLU instantiations only the run-time-choice one at width 256 gets one, and every one of round 2's set: build time.)"""
+    return (h // 32) % 4 == 0 and (act == 0 or (h <= 256 and (act == 9 or FULL)))
 
 
 def _hipcc() -> str:
@@ -316,7 +332,7 @@ def build(verbose: bool = False, jobs: int | None = None) -> Path:
         done = dict(zip(order, ex.map(lambda s: _compile(s, _deps_hash(s), verbose), order)))
     objs = [done[s] for s in srcs]
     stamp = hashlib.sha256("".join(sorted(o.name for o in objs)).encode()).hexdigest()
-    stamp_file = PKG / "_build" / "link.stamp"
+    stamp_file = PKG / "_build" / ("link_full.stamp" if FULL else "link.stamp")
     if LIB.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
         return LIB
     cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]

@@ -44,16 +44,14 @@ struct ControlArgs {
 };
 
 // words of one evaluation row of the table for real time `t_real`; `feat` = the row's time features (LDS)
-__device__ __forceinline__ void write_eval_row(const ff_adapt_config& c, float* row, int stride, float t_solver, int slot,
+__device__ __forceinline__ void write_eval_row(const ff_adapt_config& c, float* row, int stride, const float* ab, int slot,
                                                const float* cin8, const float* feat)
 {
 #pragma clang fp contract(off)
     for (int i = threadIdx.x; i < stride; i += blockDim.x) {
         float v = 0.f;
         if (i < 2) {
-            float a, b;
-            adapt::schedule_ab(c, c.sign * t_solver, &a, &b);
-            v = c.sign * (i == 0 ? a : b);
+            v = ab[i];
         } else if (i == 4) {
             v = __builtin_bit_cast(float, slot);
         } else if (i >= 8 && i < 16) {
@@ -86,6 +84,7 @@ __global__ __launch_bounds__(256) void adapt_control_kernel(const ControlArgs a)
     __shared__ double s_t, s_dt, s_h0;
     __shared__ float row_t[FF_MAX_SLOTS];                       // solver-time of each evaluation row
     __shared__ float row_cin[FF_MAX_SLOTS][8];
+    __shared__ float row_ab[FF_MAX_SLOTS][2];                   // sign * a_e, sign * b_e of each evaluation row
     __shared__ float feat[FF_MAX_SLOTS][kMaxTimeCols];
     __shared__ float tail[4][8];
 
@@ -142,6 +141,11 @@ __global__ __launch_bounds__(256) void adapt_control_kernel(const ControlArgs a)
             ts = (float)s_t;
         }
         row_t[r] = ts;
+        // the schedule scalars of the row (one thread per row: the transcendentals of six rows run side by side)
+        float sa, sb;
+        adapt::schedule_ab(c, c.sign * ts, &sa, &sb);
+        row_ab[r][0] = c.sign * sa;
+        row_ab[r][1] = c.sign * sb;
     }
     if (threadIdx.x < 32) {                                     // tail coefficients: 4 x 8 words
 #pragma clang fp contract(off)
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void adapt_control_kernel(const ControlArgs a)
     __syncthreads();
     for (int r = 0; r < n_rows; ++r) {
         const int slot = kind == adapt::kRowsAttempt ? r + 1 : (kind == adapt::kRowsDerivAtH0 ? 1 : 0);
-        write_eval_row(c, a.etab + (size_t)r * a.etab_stride, a.etab_stride, row_t[r], slot, row_cin[r], feat[r]);
+        write_eval_row(c, a.etab + (size_t)r * a.etab_stride, a.etab_stride, row_ab[r], slot, row_cin[r], feat[r]);
     }
     write_tail_row(a.etab + (size_t)n_rows * a.etab_stride, a.etab_stride, tail[0], tail[1],
                    kind == adapt::kRowsAttempt ? 0b0101u : 0u);

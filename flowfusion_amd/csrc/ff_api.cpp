@@ -113,6 +113,8 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
     // then fewer first-layer k-steps.  FF_TILE=32|16 pins the tile (experiments).
     const char* pin = getenv("FF_TILE");
     const int pin_tile = pin ? atoi(pin) : 0;
+    // FF_ACT_ANY=1 / 0 (A/B runs on a library built with FF_BUILD_FULL): only / never the run-time-choice instantiations
+    const char* pin_any = getenv("FF_ACT_ANY");
     int best = -1;
     for (int i = 0; i < ff::g_n_kernels; ++i) {
         const ff::KernelEntry& k = ff::g_kernels[i];
@@ -121,6 +123,7 @@ extern "C" int ff_mlp_plan_prec(int dim, int cond_dim, int n_hidden, const int* 
         if (k.H < wmax || k.dregs < need_d || k.cregs < need_c || k.tangents != need_t ||
             !(k.act == activation || (k.act == 9 && activation != FF_ACT_SILU))) continue;
         if (pin_tile && k.tile != pin_tile) continue;
+        if (pin_any && activation != FF_ACT_SILU && (k.act == 9) != (atoi(pin_any) != 0)) continue;
         if (best < 0) { best = i; continue; }
         const ff::KernelEntry& b = ff::g_kernels[best];
         const int kc = k.dregs * (64 / k.tile) + k.cregs * (64 / k.tile);     // first-layer features covered

@@ -179,12 +179,14 @@ class ScoreModel(nn.Module):
         attribute that can be flipped later) selects the arithmetic of the Linear layers in the fused solves:
         ``"f32"`` (default) is exact fp32, what the reference computes; ``"bf16x3"`` runs them on the bf16 matrix cores
         with every operand split into three bf16 parts and six products per term -- fp32-class accuracy (1e-7
-        relative per layer) at about twice the speed, for SiLU networks up to 256 wide, dim <= 16 (``"bf16x2"``: <= 32) (state-only and
-        Hutchinson solves and the exact trace, fixed grids and the adaptive methods, ``sample_sde``); anything else -- the
-        Hutch++ / XTrace estimators, other activations, wider networks -- raises with this setting.  ``"bf16x2"``: two bf16 parts by
-        round-to-nearest (operands to 16 significand bits, unbiased) and three products per term -- half the matrix
-        work of ``"bf16x3"``; a layer's error is ~4e-7 relative in the mean (fp32: 2e-8), end to end the sampler and
-        the log-density of the headline configuration stay at the fp32 kernel's distance from the float64 oracle."""
+        relative per layer) at about twice the speed, for the state-only solves (sampling on fixed grids and with the
+        adaptive methods, ``sample_sde``) of SiLU networks with 1-4 hidden layers up to 256 wide, dim <= 16.
+        ``"bf16x2"``: two bf16 parts by round-to-nearest (operands to 16 significand bits, unbiased) and three products per
+        term -- half the matrix work of ``"bf16x3"``; a layer's error is ~4e-7 relative in the mean (fp32: 2e-8), end to
+        end the sampler and the log-density of the headline configuration stay at the fp32 kernel's distance from the
+        float64 oracle; same networks, also the Hutchinson and exact-trace log-densities and, state-only, dim <= 32.
+        Anything else -- the Hutch++ / XTrace estimators, other activations, wider or deeper networks -- raises with these
+        settings (round 3 froze the family at what the BASELINE configurations and the reference's demos reach)."""
         super().__init__()
         self.precision = precision
         self.model = model
@@ -647,7 +649,7 @@ class ScoreModel(nn.Module):
         net = self._net()
         if net.precision != "f32":
             raise NotImplementedError(f"precision={net.precision!r}: the Hutch++ / XTrace estimators need the Jacobian output of the "
-                                      "f32 kernels (bf16x3 / bf16x2 serve hutchinson=True and the exact trace)")
+                                      "f32 kernels (bf16x2 serves hutchinson=True and the exact trace)")
         if not x0.is_cuda:
             raise RuntimeError("flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
                                f"(got a tensor on {x0.device}); there is no CPU fallback")

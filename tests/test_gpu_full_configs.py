@@ -257,11 +257,18 @@ def test_population_wrappers_under_split_precision(prec):
     base, cond = torch.randn(90, 5, device=DEV), torch.randn(90, 3, device=DEV)
     out = pm(base, cond)
     assert _native.kernel_name(pm.score_model._net().plan(0)).startswith("mlp_ode_split")
-    lp = pm.log_prob(out[:30], cond[:30])
+    if prec == "bf16x3":          # three parts: state-only kernels (round 3); a log-density never switches arithmetic silently
+        with pytest.raises(NotImplementedError, match="bf16x3"):
+            pm.log_prob(out[:30], cond[:30])
+        lp = None
+    else:
+        lp = pm.log_prob(out[:30], cond[:30])
     pm.score_model.precision = "f32"
     out32 = pm(base, cond)
     lp32 = pm.log_prob(out[:30], cond[:30])
-    assert _state_err(out, out32.cpu()) < STATE_TOL and _logp_err(lp, lp32.cpu()) < ADAPT_TOL
+    assert _state_err(out, out32.cpu()) < STATE_TOL
+    # (two adaptive solves at rtol = atol = 1e-5 on right-hand sides that differ at 1e-6: similar, not equal, step sequences)
+    assert lp is None or _logp_err(lp, lp32.cpu()) < ADAPT_TOL
 
 
 def test_population_wrapper_hutchinson_log_prob_fixed_seed():

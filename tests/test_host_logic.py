@@ -41,8 +41,12 @@ def test_library_exports_every_declared_symbol(built_library):
 def test_plan_selection_and_errors(built_library):
     p = _native.make_plan(16, 0, [256] * 4, MODE_STATE)          # bench shape: 16x16x4, two waves per SIMD
     assert (p.tile, p.width, p.dregs, p.cregs) == (16, 256, 4, 0)
-    p = _native.make_plan(2, 0, [128] * 3, MODE_HUTCH)            # narrower nets: 32x32x2 kernels
-    assert (p.tile, p.width, p.dregs) == (32, 128, 4)
+    p = _native.make_plan(2, 0, [128] * 3, MODE_HUTCH)            # the notebooks' 3x128: 16x16x4, two waves per SIMD (round 3)
+    assert (p.tile, p.width, p.dregs) == (16, 128, 4)
+    p = _native.make_plan(2, 0, [64] * 3, MODE_HUTCH)             # narrower nets, and 128-wide ones beyond 16 dimensions: 32x32x2
+    assert (p.tile, p.width, p.dregs) == (32, 64, 4)
+    p = _native.make_plan(20, 0, [128] * 3, MODE_STATE)
+    assert (p.tile, p.width, p.dregs) == (32, 128, 16)
     p = _native.make_plan(32, 8, [200, 100], MODE_STATE)          # ragged widths pad to the max
     assert (p.width, p.cond_dim) == (256, 8) and p.dregs * (64 // p.tile) >= 32
     p = _native.make_plan(48, 0, [256, 256], MODE_EXACT)          # many dimensions on a 256-wide net stay 256 wide

@@ -25,6 +25,14 @@ DEV = "cuda"
 STATE_TOL = 2e-5
 LOGP_TOL = 2e-5
 PRECS = ["bf16x3", "bf16x2"]
+# log-densities (Hutchinson column pairs, exact trace) under precision=: the two-part kernels.  Round 3 froze the three-part
+# option at its state-only kernels (the second record of the headline workload): its divergence modes raise.
+LOGP_PRECS = ["bf16x2"]
+
+
+def _logp_raises(fn):
+    with pytest.raises(NotImplementedError, match="bf16x3"):
+        fn()
 
 
 def _kidx(s, q, j):
@@ -47,11 +55,14 @@ def test_plan_and_packer_roundtrip(built_library):
     plan = net.plan(MODE_STATE)
     assert (plan.precision, plan.tile, plan.width, plan.dregs, plan.cregs, plan.n_hidden) == (1, 32, 256, 8, 8, 3)
     assert _native.kernel_name(plan) == "mlp_ode_split_h256_n3_t0"
-    assert _native.kernel_name(net.plan(MODE_HUTCH)) == "mlp_ode_split_h256_n3_t1"
     assert _native.samples_per_workgroup(plan, MODE_STATE) == 128
-    assert _native.samples_per_workgroup(net.plan(MODE_HUTCH), MODE_HUTCH) == 64
+    _logp_raises(lambda: net.plan(MODE_HUTCH))                       # three parts: state-only kernels since round 3
+    sm2 = D.ScoreModel(sm.model, D.VPSDE(), no_sigma=True, precision="bf16x2").eval()
+    n2 = sm2._net()
+    assert _native.kernel_name(n2.plan(MODE_HUTCH)) == "mlp_ode_split2_h256_n3_t1"
+    assert _native.samples_per_workgroup(n2.plan(MODE_HUTCH), MODE_HUTCH) == 64
+    assert n2.wpack("cpu", MODE_HUTCH) is n2.wpack("cpu", MODE_STATE)      # one layout for both instantiations
     pack = net.wpack("cpu", MODE_STATE)
-    assert net.wpack("cpu", MODE_HUTCH) is pack                      # one layout for both instantiations
     words = pack.numpy().view(np.uint32)
     NR, NS, NH, H = 16, 8, 3, 256
     n_gran = (NR + (NH - 1) * NR * NS + NS) // 8
@@ -190,9 +201,9 @@ def test_split_precision_scope_and_errors(built_library):
     mk = lambda **kw: _native.make_plan(kw.get("dim", 16), kw.get("cond", 0), kw.get("hidden", [256] * 4), kw.get("mode", MODE_STATE),
                                         kw.get("act", (_native.ACT_SILU, 0.0, 0.0)), _native.PREC_BF16X3)
     assert mk().precision == 1
-    px = mk(mode=MODE_EXACT)
-    assert (px.tile, _native.kernel_name(px)) == (16, "mlp_ode_split_h256_n4_t2") and _native.samples_per_workgroup(px, MODE_EXACT) == 8
-    for bad in (dict(dim=17), dict(cond=17), dict(hidden=[300, 300]), dict(hidden=[64] * 5),
+    px = _native.make_plan(16, 0, [256] * 4, MODE_EXACT, (_native.ACT_SILU, 0.0, 0.0), _native.PREC_BF16X2)
+    assert (px.tile, _native.kernel_name(px)) == (16, "mlp_ode_split2_h256_n4_t2") and _native.samples_per_workgroup(px, MODE_EXACT) == 8
+    for bad in (dict(dim=17), dict(cond=17), dict(hidden=[300, 300]), dict(hidden=[64] * 5), dict(mode=MODE_EXACT), dict(mode=MODE_HUTCH),
                 dict(act=(_native.ACT_TANH, 0.0, 0.0))):
         with pytest.raises(NotImplementedError, match="bf16x3"):
             mk(**bad)
@@ -243,6 +254,8 @@ def test_split_against_golden_hybrids(name, prec, built_library):
         m, opts = run["method"], {"step_size": run["step_size"]}
         x0, _ = sm.sample_ode_from_base(a["base"].to(DEV), conditional=cond_d, method=m, options=opts)
         assert _state_err(x0, a[f"sample_{m}"]) < STATE_TOL, (name, m)
+        if prec not in LOGP_PRECS:
+            continue
         sm.hutch = True
         xd = a[f"x_data_{m}"].to(DEV)
         tab = sm._ode_table(torch.tensor([float(sm.sde.epsilon), 1.0]), m, opts, 1)
@@ -285,6 +298,8 @@ def test_split_sampling_and_log_prob_against_oracle(name, prec, built_library):
     Bl = min(B, 256)
     x0 = torch.randn(Bl, Dm) * 0.8 + 0.3
     torch.manual_seed(99)
+    if prec not in LOGP_PRECS:
+        return _logp_raises(lambda: sm.log_prob(x0.to(DEV), conditional=None if cd is None else cd[:Bl], method=method, options=opts))
     lp = sm.log_prob(x0.to(DEV), conditional=None if cd is None else cd[:Bl], method=method, options=opts)
     e = sm.e.cpu()
     ref64 = so64.log_prob(x0.double(), None if cond is None else cond[:Bl].double(), method, opts, "hutch", e.double()).float()
@@ -311,17 +326,19 @@ def test_split_adaptive_default_calls(prec, built_library):
     stats = dict(sm.last_solver_stats)
     ref = so64.sample_ode_from_base(base.double(), cond.double(), "dopri5", None, atol=1e-4, rtol=1e-4).float()
     assert _state_err(x0, ref) < 2e-4
-    sm.hutch = True
-    xd = torch.randn(64, 16) * 3
-    torch.manual_seed(9)
-    lp = sm.log_prob(xd.to(DEV), conditional=cond[:64].to(DEV))
-    e = sm.e.cpu()
-    ref = so64.log_prob(xd.double(), cond[:64].double(), "dopri5", {"min_step": 1e-6}, "hutch", e.double(), atol=1e-4, rtol=1e-4).float()
-    assert _logp_err(lp, ref) < 2e-4
-    sm.hutch = False
+    if prec in LOGP_PRECS:
+        sm.hutch = True
+        xd = torch.randn(64, 16) * 3
+        torch.manual_seed(9)
+        lp = sm.log_prob(xd.to(DEV), conditional=cond[:64].to(DEV))
+        e = sm.e.cpu()
+        ref = so64.log_prob(xd.double(), cond[:64].double(), "dopri5", {"min_step": 1e-6}, "hutch", e.double(), atol=1e-4, rtol=1e-4).float()
+        assert _logp_err(lp, ref) < 2e-4
+        sm.hutch = False
     sm.precision = "f32"
     y0, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV))
-    assert sm.last_solver_stats == stats and _state_err(x0, y0.cpu()) < STATE_TOL
+    # (the same controller on fp32-class right-hand sides: a similar step sequence, see test_split_exact_trace)
+    assert abs(sm.last_solver_stats["attempts"] - stats["attempts"]) <= 3 and _state_err(x0, y0.cpu()) < 5e-4
 
 
 @pytest.mark.gpu
@@ -366,7 +383,7 @@ EXACT = {
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", LOGP_PRECS)
 @pytest.mark.parametrize("name", list(EXACT))
 def test_split_exact_trace(name, prec, built_library):
     """The reference's default divergence (exact trace, diffusion.py:483-503) on the split kernels: a value column and its
@@ -490,6 +507,8 @@ def test_split_ragged_batches(B, prec, built_library):
     got, _ = sm.sample_ode_from_base(base.to(DEV), method="rk4", options=opts)
     assert _state_err(got, so32.sample_ode_from_base(base, None, "rk4", opts)) < STATE_TOL
     sm.hutch = True
+    if prec not in LOGP_PRECS:
+        return _logp_raises(lambda: sm.log_prob(base.to(DEV), method="euler", options=opts))
     lp = sm.log_prob(base.to(DEV), method="euler", options=opts)
     assert _logp_err(lp, so32.log_prob(base, None, "euler", opts, "hutch", sm.e.cpu())) < LOGP_TOL
 
@@ -511,6 +530,11 @@ def test_split_flows_and_wrappers(prec, built_library):
     assert _state_err(got, fo64.sample(xT.double(), cond.double(), "rk4", opts).float()) < STATE_TOL
     x = xT[:48] * f.target_scale.cpu() + f.target_shift.cpu()
     torch.manual_seed(3)
+    if prec not in LOGP_PRECS:
+        _logp_raises(lambda: f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts, hutchinson=True))
+        ga = f.sample(xT.to(DEV), cond.to(DEV))                                        # the default call: adaptive dopri5
+        assert _state_err(ga, fo64.sample(xT.double(), cond.double(), "dopri5", None, atol=1e-9, rtol=1e-7).float()) < 2e-4
+        return
     lp = f.log_prob(x.to(DEV), cond[:48].to(DEV), method="rk4", options=opts, hutchinson=True)
     f.precision = "f32"
     torch.manual_seed(3)
@@ -599,7 +623,7 @@ def test_split_random_shapes_against_oracle(built_library):
         assert _state_err(x0, so64.sample_ode_from_base(z.double(), c64, method, opts).float()) < STATE_TOL, tag
         kernels.add(_native.kernel_name(sm._net().plan(0)))
         mode = rnd.choice(["hutch", "exact"])
-        if Dm <= 16:
+        if Dm <= 16 and prec in LOGP_PRECS:
             sm.hutch = mode == "hutch"
             xd = torch.randn(B, Dm) * 0.5
             lp = sm.log_prob(xd.to(DEV), conditional=cd, method=method, options=opts)
