@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int t = 0; t < DT; ++t) ks[SL(s, cb, t)] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < H; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
+    for (int i = threadIdx.x; i < H + kZeroSkew / 4; i += 256) ((float*)(lds + M.zero))[i] = 0.f;
     {
         const float* bsrc = args.wpack + (size_t)stream_words(NH, NP, DT, HW);
         const int nb = (NH - 1) * H + 16 * DT;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
     __syncthreads();
 
     // bias of row tile rt of the vector at LDS byte `base` (tangent lanes read the zero page): accumulator register order
-    const int zsel = M.zero + qd * 16;
+    const int zsel = M.zero + kZeroSkew + qd * 16;     // (skewed against the bias vectors' banks: ff_split_layout.h)
     auto bias_tile = [&](int base, int rt) __attribute__((always_inline)) {
         const int a = (TANGENTS && is_tangent) ? zsel : base + qd * 16;
         return *(const f32x4*)(lds + a + 64 * rt);

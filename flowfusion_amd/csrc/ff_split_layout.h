@@ -73,13 +73,20 @@ FF_HD constexpr size_t total_words(int n_hidden, int parts, int dt = 1, int w = 
     return stream_words(n_hidden, parts, dt, w) + (size_t)(n_hidden - 1) * w + 16 * dt;
 }
 
+// Tangent lanes read zeros where value lanes read a bias.  Every bias vector starts at a multiple of 256 B (one LDS bank
+// row), and so did the zero page: in each 16-lane group of a ds_read_b128 the value lanes of a quad and the tangent lanes
+// of the same quad then hit the same four banks at two addresses -- a 2-way conflict on every bias read of the
+// divergence kernels (round 2 PMC: SQ_LDS_BANK_CONFLICT 6.8e9 of 1.03e11 LDS cycles in the Hutchinson kernel, 0 in the
+// state-only one).  The tangent lanes' reads are therefore skewed by a quarter of the bank row.
+constexpr int kZeroSkew = 64;
+
 // LDS map (byte offsets) of a workgroup of 4 wavefronts
 struct LdsMap {
     int wbuf;    // kBuffers weight granules
     int slots;   // Runge-Kutta stage slots + the parked stage input y + the state x: (slots + 2) x 2 column blocks x dt x 256 threads x 16 B
     int c1;      // 2 x 1 KiB: first-layer bias of the current / next evaluation (one LDS-DMA fragment each)
     int hbias;   // (NH-1) x H floats + 16 dt: hidden->hidden and output biases
-    int zero;    // H floats of zeros (what tangent columns read instead of a bias)
+    int zero;    // H + 16 floats of zeros (what tangent columns read instead of a bias, 64 B into the page: see kZeroSkew)
     int total;
 };
 FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts, int dt = 1, int slots = 0)
@@ -91,7 +98,7 @@ FF_HD constexpr LdsMap lds_map(int H, int n_hidden, int parts, int dt = 1, int s
     m.hbias = m.c1 + 2 * 1024;
     const int nh1 = n_hidden - 1 > 1 ? n_hidden - 1 : 1;
     m.zero = m.hbias + nh1 * H * 4 + 256 * 4;    // (a spare KiB: a tile read of the 16 dt output biases stays inside)
-    m.total = m.zero + 256 * 4;
+    m.total = m.zero + 256 * 4 + 256;
     return m;
 }
 

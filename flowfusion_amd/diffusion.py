@@ -435,7 +435,10 @@ class ScoreModel(nn.Module):
         draws them on the model's device (one prior draw, then one ``randn_like`` per step), so a given
         ``torch.manual_seed`` reproduces the reference's stream on that device.  If a step produces a NaN the
         reference prints a message, stops and returns that step's mean (:560-563); so does this method (the
-        step is located after the fact, by re-running a prefix of the launch that reported it).
+        step is located after the fact, by re-running a prefix of the launch that reported it).  One difference after
+        such a stop: the reference stops DRAWING at the failing step, here the normals of the whole chunk (and, with two
+        chunks in flight, of the next one) have been drawn by then, so torch's generator is further along than the
+        reference's would be -- the returned tensor is the reference's, the generator state afterwards is not.
 
         Extensions: ``noise="philox"`` draws the per-step normals inside the kernel (counter-based, keyed by
         ``seed`` and the global sample index ``sample_offset + row``; include/flowfusion_amd.h): no noise
