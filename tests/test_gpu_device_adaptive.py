@@ -253,6 +253,33 @@ def test_large_batch_default_log_prob_runs_in_one_or_two_chunks():
     assert torch.equal(a, b) and st == sm.last_solver_stats and st["chunks"] <= 3 and torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("B", [1, 3, 17])
+def test_tiny_batches_on_the_device_controller(B, monkeypatch):
+    """One, three, seventeen rows (unaligned array ends, a single tile, one reduction block): sampling and exact-trace
+    log-density under both controllers and against the oracle; an empty batch returns empty tensors."""
+    sm, so32, _ = _seeded_score_model(3, 2, [64, 64], "VESDE", False, 404)
+    torch.manual_seed(B)
+    base, cond = torch.randn(B, 3), torch.randn(B, 2)
+
+    def sample():
+        x, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV))
+        return x, dict(sm.last_solver_stats)
+    (a, sa), (b, sb) = _both(monkeypatch, sample)
+    # (with a handful of rows nothing averages the step control: the two controllers' step sizes differ in the seventh digit
+    # and the solutions by a fraction of rtol = 1e-4 -- the bar between them is the solver tolerance's, not 1e-5)
+    assert a.shape == (B, 3) and _same_counts(sa, sb) and _state_err(a, b.cpu()) < ADAPT_TOL
+    assert _state_err(a, so32.sample_ode_from_base(base, cond, "dopri5", None)) < ADAPT_TOL
+
+    def logp():
+        return sm.log_prob(base.to(DEV) * 0.5, conditional=cond.to(DEV)), dict(sm.last_solver_stats)
+    (a, sa), (b, sb) = _both(monkeypatch, logp)
+    assert a.shape == (B, 1) and _same_counts(sa, sb) and _logp_err(a, b.cpu()) < ADAPT_TOL
+    assert _logp_err(a, so32.log_prob(base * 0.5, cond, "dopri5", {"min_step": 1e-6}, "exact", None)) < ADAPT_TOL
+    if B == 1:
+        e, _ = sm.sample_ode_from_base(base[:0].to(DEV), conditional=cond[:0].to(DEV))
+        assert e.shape == (0, 3) and sm.last_solver_stats["attempts"] == 0
+
+
 # ---- kernel-level guards ----------------------------------------------------------------------------------------------
 def _raw_launch(sm, x, table, gate=None, stage_slots=0, mode=0, status=None):
     from flowfusion_amd import _native
