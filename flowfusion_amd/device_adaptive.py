@@ -29,6 +29,7 @@ from ._native import MODE_EXACT, MODE_STATE
 FIRST_CHUNK = 16          # attempted steps enqueued before the first look at the state
 TRACE = None              # diagnostics: a list collects (attempts, accepted, t, dt, last error ratio) after every attempted step
                           # (one attempt per chunk while it is set; scratch/diag_adaptive_pair.py)
+TRACE_ROWS = False        # ... and a host copy of the evaluation table the controller wrote for the NEXT attempt (tests)
 MAX_CHUNK = 64
 MAX_TIME_COLS = 64        # kMaxTimeCols of ff_adaptive.hip
 
@@ -49,9 +50,15 @@ def host_controller_forced() -> bool:
     return os.environ.get("FF_HOST_CONTROLLER", "") not in ("", "0")
 
 
-def supported(spec: Optional[ScheduleSpec], x: torch.Tensor) -> bool:
-    return (spec is not None and x.is_cuda and not host_controller_forced()
-            and spec.w0t.shape[1] <= MAX_TIME_COLS)
+def supported(spec: Optional[ScheduleSpec], x: torch.Tensor, net=None, mode: int = MODE_STATE) -> bool:
+    """The device controller can run this solve: a schedule it knows, at most 64 time columns in the first layer, and -- for
+    the exact trace -- at most FF_ADAPT_MAX_PASSES unit-tangent passes per attempted step (more than 120 dimensions on the
+    16-column tile).  Otherwise the host controller takes it."""
+    if spec is None or not x.is_cuda or host_controller_forced() or spec.w0t.shape[1] > MAX_TIME_COLS:
+        return False
+    if net is not None and mode == MODE_EXACT and len(list(_passes(net, net.plan(mode)))) > _native.ADAPT_MAX_PASSES:
+        return False
+    return True
 
 
 def build_config(spec: ScheduleSpec, sign: float, method: str, rtol: float, atol: float, options: Optional[dict],
@@ -194,7 +201,8 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
                 err.solver_stats = {"attempts": int(st.n_attempts), "accepted": int(st.n_accepted), "chunks": chunks}
                 raise err
             if TRACE is not None:
-                TRACE.append((int(st.n_attempts), int(st.n_accepted), float(st.t), float(st.dt), float(st.last_ratio)))
+                TRACE.append((int(st.n_attempts), int(st.n_accepted), float(st.t), float(st.dt), float(st.last_ratio))
+                             + ((etab.view(8, 32 + width).cpu().clone(),) if TRACE_ROWS else ()))
             if st.done:
                 break
             if not st.active:

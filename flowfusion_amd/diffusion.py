@@ -389,7 +389,7 @@ class ScoreModel(nn.Module):
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
             spec = self._device_schedule(x.device) if x.is_cuda else None
-            if device_adaptive.supported(spec, x):
+            if device_adaptive.supported(spec, x, net, mode):
                 # the whole loop on the device: attempts, error norms, step control, the next attempt's table rows
                 y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]),
                                                      rtol, atol, options, method, cond=cond, probe=probe)

@@ -129,11 +129,13 @@ class _FlowBase(nn.Module):
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
             # the reference keeps the raw conditional in the solver state (flow.py:779-796, 855-881)
             extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
-            if x.is_cuda and not device_adaptive.host_controller_forced():
-                # the whole loop on the device (device_adaptive.py): xdot = NET([x, t, cond]) -> a = 0, b = 1, c1 = w_t t + b1
+            spec = None
+            if x.is_cuda:
                 D = self.target_dimension
                 w0t, b0 = net.time_columns(x.device, D, D + 1)
                 spec = device_adaptive.ScheduleSpec(_native.SCHED_FLOW, (0.0, 0.0, 0.0), True, None, 0.0, w0t, b0)
+            if device_adaptive.supported(spec, x, net, mode):
+                # the whole loop on the device (device_adaptive.py): xdot = NET([x, t, cond]) -> a = 0, b = 1, c1 = w_t t + b1
                 y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]), rtol, atol,
                                                      options, method, cond=cond, probe=probe, norm_only=extra)
                 self.last_solver_stats = stats

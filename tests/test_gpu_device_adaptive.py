@@ -253,6 +253,66 @@ def test_large_batch_default_log_prob_runs_in_one_or_two_chunks():
     assert torch.equal(a, b) and st == sm.last_solver_stats and st["chunks"] <= 3 and torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("case", ["VESDE", "VPSDE", "SUBVPSDE", "flow"])
+def test_rows_written_by_the_controller_equal_the_host_rows(case):
+    """The evaluation table the controller kernel writes for the next attempt, read back after every attempted step, against
+    the rows the host controller builds for the same (t, dt) (fused.make_step + the torch schedule): integer words, stage
+    coefficients and tail rows bit for bit, a_e / b_e to two ulps, c1 to the rounding of an 8-term fp32 sum (device vs
+    torch's vectorised sin / cos / exp / pow)."""
+    from flowfusion_amd import adaptive, device_adaptive
+    from flowfusion_amd import flow as Fm
+    torch.manual_seed(12)
+    if case == "flow":
+        model = Fm.ConditionalODEFlow(5, 2, [96, 128]).eval().to(DEV)
+        x, cond = torch.randn(300, 5, device=DEV), torch.randn(300, 2, device=DEV)
+        run = lambda: model.sample(x, cond, atol=1e-7, rtol=1e-7)
+        net = model._net()
+        first = net.first_layer_cpu()
+        sched, sign = (lambda tr: model._schedule(tr, first)), -1.0
+    else:
+        sm, _, _ = _seeded_score_model(5, 2, [96, 128], case, case == "VPSDE", 55)
+        x, cond = torch.randn(300, 5, device=DEV), torch.randn(300, 2, device=DEV)
+        net = sm._net()
+        host = sm._schedule_inputs()
+        if case == "VESDE":
+            run = lambda: sm.sample_ode_from_base(x, conditional=cond, atol=1e-7, rtol=1e-7)
+            sched, sign = (lambda tr: sm._schedule(tr, "ode", host)[:3]), -1.0
+        else:       # (a random-init VP reverse flow diverges: the forward solve of log_prob walks the same schedule upwards)
+            sm.hutch = True
+            run = lambda: sm.log_prob(x * 0.5, conditional=cond, atol=1e-6, rtol=1e-6)
+            sched, sign = (lambda tr: sm._schedule(tr, "ode", host)[:3]), 1.0
+    device_adaptive.TRACE, device_adaptive.TRACE_ROWS = [], True
+    try:
+        run()
+        trace = device_adaptive.TRACE
+    finally:
+        device_adaptive.TRACE, device_adaptive.TRACE_ROWS = None, False
+    assert len(trace) >= 3
+    # the host controller's rows for the same step: capture what make_step hands to the launcher
+    captured = {}
+
+    def launcher(y, k1, kl1, lp0, rows, n_aux, first_, count, **kw):
+        captured["rows"] = rows.clone()
+        return torch.zeros(n_aux, 1, 5), None
+    step = net.make_step(sched, sign, 0, "cpu", cond=None, probe=None, launcher=launcher)      # (rows do not depend on the mode)
+    helper = adaptive.Dopri5(step, False, 1e-5, 1e-5, None)
+    width = net.plan(0).width
+    checked = 0
+    for (n_att, n_acc, t, dt, ratio, rows_dev) in trace[:-1]:          # the last entry is the finished solve: no next attempt
+        helper._attempt(t, dt, t + dt, torch.zeros(1, 5), None, torch.zeros(1, 5), None)
+        rows_host = captured["rows"]                                    # [6 + 2, 32 + width]
+        dev = rows_dev[: rows_host.shape[0]]
+        hi, di = rows_host.view(torch.int32), dev.view(torch.int32)
+        assert torch.equal(hi[:, 3:6], di[:, 3:6])                      # flags / use_y bits, slots, noise index
+        assert torch.equal(rows_host[:, 8:24], dev[:, 8:24])            # stage and tail coefficients: bit for bit
+        assert torch.equal(rows_host[:, 24:32], dev[:, 24:32]) and torch.equal(rows_host[6:, 32:], dev[6:, 32:])
+        # (sub-VP: sigma = 1 - exp(-x) and 1 - decay cancel at small t, so one ulp of `exp` shows up amplified in b_e)
+        torch.testing.assert_close(dev[:6, :2], rows_host[:6, :2], rtol=2e-5 if case == "SUBVPSDE" else 5e-7, atol=0)
+        torch.testing.assert_close(dev[:6, 32:32 + width], rows_host[:6, 32:32 + width], rtol=2e-6, atol=3e-6)
+        checked += 1
+    assert checked >= 2
+
+
 @pytest.mark.parametrize("B", [1, 3, 17])
 def test_tiny_batches_on_the_device_controller(B, monkeypatch):
     """One, three, seventeen rows (unaligned array ends, a single tile, one reduction block): sampling and exact-trace
