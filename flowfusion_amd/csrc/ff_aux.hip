@@ -66,19 +66,28 @@ __global__ __launch_bounds__(256) void stage_combine_kernel(const CombineArgs a)
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n4 = a.vec_ok ? a.n / 4 : 0;
-    for (long long i = tid; i < n4; i += stride) {
+    // two 16-byte elements per thread and trip: every array's two loads are in flight before the first is used (a one-term
+    // combine otherwise waits on two loads per trip)
+    auto combine = [&](long long i) __attribute__((always_inline)) {
         f32x4a v = a.x ? a.x_coef * ((const f32x4a*)a.x)[i] : f32x4a{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < FF_MAX_SLOTS; ++s)
             if (a.k[s]) v += a.coef[s] * ((const f32x4a*)a.k[s])[i];
-        ((f32x4a*)a.out)[i] = v;
+        return v;
+    };
+    long long i = tid;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4a v0 = combine(i), v1 = combine(i + stride);
+        ((f32x4a*)a.out)[i] = v0;
+        ((f32x4a*)a.out)[i + stride] = v1;
     }
-    for (long long i = 4 * n4 + tid; i < a.n; i += stride) {     // unaligned input or the last n % 4 elements
-        float v = a.x ? a.x_coef * a.x[i] : 0.f;
+    if (i < n4) ((f32x4a*)a.out)[i] = combine(i);
+    for (long long j = 4 * n4 + tid; j < a.n; j += stride) {     // unaligned input or the last n % 4 elements
+        float v = a.x ? a.x_coef * a.x[j] : 0.f;
 #pragma unroll
         for (int s = 0; s < FF_MAX_SLOTS; ++s)
-            if (a.k[s]) v = __builtin_fmaf(a.coef[s], a.k[s][i], v);
-        a.out[i] = v;
+            if (a.k[s]) v = __builtin_fmaf(a.coef[s], a.k[s][j], v);
+        a.out[j] = v;
     }
 }
 

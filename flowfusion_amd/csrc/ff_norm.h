@@ -65,34 +65,57 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const f32x4a zero4 = f32x4a{0.f, 0.f, 0.f, 0.f};
+    // The finiteness check of an attempted step looks at y1, which is also the second scale array of the first term
+    // (err / (atol + rtol max(|y0|, |y1|))): when `check` IS that array the check rides in the term's pass instead of reading
+    // the array a second time (12 instead of 16 bytes per element, one pass instead of two).
+    const bool fold_check = a.n_terms > 0 && a.check != nullptr && a.check == a.s1[0] && a.n_check == a.n[0];
+    double bad = 0.0;
     for (int t = 0; t < a.n_terms; ++t) {
         double acc = 0.0;
         const float* num = a.num[t]; const float* sub = a.sub[t]; const float* s0 = a.s0[t]; const float* s1 = a.s1[t];
         const long long n4 = a.vec_ok[t] ? a.n[t] / 4 : 0;
-        for (long long i = tid; i < n4; i += stride) {
+        const bool chk = fold_check && t == 0;
+        // two 16-byte elements per thread and trip (up to eight loads in flight).
+        // The order in which a thread adds its elements is fixed by (grid, n) alone, so equal inputs still give equal sums.
+        auto term4 = [&](long long i) __attribute__((always_inline)) {
             const f32x4a vn = ((const f32x4a*)num)[i];
             const f32x4a vs = sub ? ((const f32x4a*)sub)[i] : zero4;
             const f32x4a v0 = ((const f32x4a*)s0)[i];
             const f32x4a v1 = s1 ? ((const f32x4a*)s1)[i] : zero4;
+            double r = 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc += scaled_sq(vn[j], vs[j], v0[j], v1[j], a.atol, a.rtol);
+            for (int j = 0; j < 4; ++j) {
+                r += scaled_sq(vn[j], vs[j], v0[j], v1[j], a.atol, a.rtol);
+                if (chk) bad += (v1[j] - v1[j] == 0.f) ? 0.0 : 1.0;        // NaN or infinity
+            }
+            return r;
+        };
+        long long i = tid;
+        for (; i + stride < n4; i += 2 * stride) {
+            const double r0 = term4(i), r1 = term4(i + stride);
+            acc += r0;
+            acc += r1;
         }
-        for (long long i = 4 * n4 + tid; i < a.n[t]; i += stride)      // unaligned input or the last n % 4 elements
+        if (i < n4) acc += term4(i);
+        for (long long i = 4 * n4 + tid; i < a.n[t]; i += stride) {    // unaligned input or the last n % 4 elements
             acc += scaled_sq(num[i], sub ? sub[i] : 0.f, s0[i], s1 ? s1[i] : 0.f, a.atol, a.rtol);
+            if (chk) bad += (s1[i] - s1[i] == 0.f) ? 0.0 : 1.0;
+        }
         const double tot = block_sum(acc, sh);
         if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
     }
     {
-        double bad = 0.0;
-        const long long n4 = a.check_vec_ok ? a.n_check / 4 : 0;
-        for (long long i = tid; i < n4; i += stride) {
-            const f32x4a v = ((const f32x4a*)a.check)[i];
+        if (!fold_check) {
+            const long long n4 = a.check_vec_ok ? a.n_check / 4 : 0;
+            for (long long i = tid; i < n4; i += stride) {
+                const f32x4a v = ((const f32x4a*)a.check)[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bad += (v[j] - v[j] == 0.f) ? 0.0 : 1.0;        // NaN or infinity
-        }
-        for (long long i = 4 * n4 + tid; i < a.n_check; i += stride) {
-            const float v = a.check[i];
-            bad += (v - v == 0.f) ? 0.0 : 1.0;
+                for (int j = 0; j < 4; ++j) bad += (v[j] - v[j] == 0.f) ? 0.0 : 1.0;        // NaN or infinity
+            }
+            for (long long i = 4 * n4 + tid; i < a.n_check; i += stride) {
+                const float v = a.check[i];
+                bad += (v - v == 0.f) ? 0.0 : 1.0;
+            }
         }
         const double tot = block_sum(bad, sh);
         if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
