@@ -209,3 +209,114 @@ def test_config_rejects_what_the_host_controller_rejects(built_library):
     cfg, _ = _config(spec, -1.0, "fehlberg2", rtol=1e-3, atol=1e-4, options={"min_step": 1e-6})
     assert (cfg.n_stages, cfg.order, cfg.sign, cfg.min_step) == (3, 2, -1.0, 1e-6) and math.isnan(cfg.first_step)
     assert cfg.max_num_steps == 2 ** 31 - 1 and cfg.max_step == float("inf")
+
+
+# ---- a whole solve, walked on the CPU with the device path's arithmetic ---------------------------------------------------
+def _walk(lib, sm, net, mode, sign, x, lp, t0, t_end, rtol, atol, options, cond=None, probe=None):
+    """An adaptive solve as ff_mlp_ode_adaptive runs it, on the CPU: evaluation rows from ff_adapt_host_row (the schedule
+    arithmetic the controller kernel compiles), every decision from ff_adapt_host_transition (the control law it
+    compiles), the fused launches from the kernel-semantics emulator, norms / commit / dense output as the kernels compute
+    them (adaptive.Dopri5's CPU statements of the same).  Returns (y, lp, state)."""
+    from tests import _emulator as E
+    from flowfusion_amd.fused import MODE_STATE
+    spec = sm._device_schedule("cpu")
+    keep = []
+    cfg = device_adaptive.build_config(spec, sign, "dopri5", rtol, atol, options, keep)
+    H = spec.w0t.shape[0]
+
+    def sched(t_real):                       # (a, b, c1) of fused.make_step's contract, from the C rows
+        a, b, c1 = torch.empty_like(t_real), torch.empty_like(t_real), torch.empty(t_real.numel(), H)
+        for i, t in enumerate(t_real.tolist()):
+            ao, bo = ctypes.c_float(), ctypes.c_float()
+            assert lib.ff_adapt_host_row(ctypes.byref(cfg), t, ctypes.byref(ao), ctypes.byref(bo), c1[i].data_ptr()) == 0
+            a[i], b[i] = sign * ao.value, sign * bo.value          # the C row carries the reversal sign already
+        return a, b, c1
+    plan = _native.plan_words(net.plan(mode))
+    wpack = net.wpack("cpu", mode)
+    launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count: E.emulate_step(
+        plan, wpack, etab, y, cond, probe, k1, kl1, lp0, mode, n_aux, first, count)
+    step = net.make_step(sched, sign, mode, "cpu", cond=cond, probe=probe, launcher=launcher)
+    has_lp = mode != MODE_STATE
+    h = adaptive.Dopri5(step, has_lp, rtol, atol, options)              # its kernels' CPU statements; NOT its control flow
+    f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
+    parts = lambda *ps: [p for p in ps if p is not None]
+    st = _native.AdaptState()
+    st.t, st.t_prev, st.t_end, st.active = t0, t0, t_end, 1
+    y, f0, fl0 = x, None, None
+    f0, fl0 = h._deriv(t0, y, lp)
+    ys, fs = parts(y, lp), parts(f0, fl0)
+    scale = [atol + p.abs() * rtol for p in ys]
+    d0 = f32(adaptive._mixed_norm([a / s for a, s in zip(ys, scale)]))
+    d1 = f32(adaptive._mixed_norm([a / s for a, s in zip(fs, scale)]))
+    assert lib.ff_adapt_host_transition(ctypes.byref(cfg), ctypes.byref(st), 1, (ctypes.c_float * 2)(d0, d1)) == 1
+    f1, fl1 = h._deriv(f32(t0) + st.h0, y, lp, k1=f0, kl1=fl0, h=st.h0)
+    d2n = f32(adaptive._mixed_norm([(a - b) / s for a, b, s in zip(parts(f1, fl1), fs, scale)]))
+    go = lib.ff_adapt_host_transition(ctypes.byref(cfg), ctypes.byref(st), 2, (ctypes.c_float * 2)(d2n, 0.0))
+    last = None
+    while go == 1:
+        aux, aux_lp = h._attempt(st.t, st.dt, st.t + st.dt, y, lp, f0, fl0)
+        y1, f1, ymid, yerr = aux[0], aux[1], aux[2], aux[3]
+        terms = [(yerr, None, y, y1)]
+        if has_lp:
+            terms.append((aux_lp[3], None, lp, aux_lp[0]))
+        ratio, bad = h._norms(terms, check=y1)
+        before = st.n_accepted
+        go = lib.ff_adapt_host_transition(ctypes.byref(cfg), ctypes.byref(st), 3, (ctypes.c_float * 2)(f32(ratio), 1.0 if bad else 0.0))
+        if st.n_accepted > before:           # accepted: what the buffers hold for the dense output
+            last = (y, y1, ymid, f0, f1, (lp, aux_lp[0], aux_lp[2], fl0, aux_lp[1]) if has_lp else None)
+        if st.commit:
+            y, f0 = y1, f1
+            if has_lp:
+                lp, fl0 = aux_lp[0], aux_lp[1]
+    if not st.done:
+        return None, None, st
+    xq = (st.t_end - st.t_prev) / (st.t - st.t_prev)                     # adapt_finish_kernel
+    ya, yb, ym, fa, fb, lps = last
+    out = h._fit_eval(ya, yb, ym, fa, fb, st.dt_prev, xq)
+    out_lp = h._fit_eval(*lps[:3], lps[3], lps[4], st.dt_prev, xq) if has_lp else None
+    return out, out_lp, st
+
+
+@pytest.mark.parametrize("case", ["ve_sample", "vp_hutch", "subvp_exact_cond"])
+def test_cpu_walk_of_the_device_path_matches_oracle_and_host_controller(case, built_library):
+    from tests._util import max_rel, score_oracle
+    from tests.test_host_logic import _cpu_launcher
+    from flowfusion_amd.fused import MODE_EXACT, MODE_HUTCH, MODE_STATE
+    torch.manual_seed(3)
+    meta = {"ve_sample": dict(D=6, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=True),
+            "vp_hutch": dict(D=3, C=0, E=8, units=[64, 64], sde="VPSDE", sde_kw={}, no_sigma=True),
+            "subvp_exact_cond": dict(D=4, C=2, E=8, units=[64], sde="SUBVPSDE", sde_kw={}, no_sigma=False)}[case]
+    sm = D.ScoreModel(D.MLP(meta["D"], meta["C"], meta["E"], meta["units"]), getattr(D, meta["sde"])(), no_sigma=meta["no_sigma"]).eval()
+    so = score_oracle(meta, {k: v.detach().clone() for k, v in sm.state_dict().items()}, torch.float64)
+    net = sm._net()
+    B = 7
+    x = torch.randn(B, meta["D"])
+    cond = torch.randn(B, meta["C"]) if meta["C"] else None
+    eps = float(sm.sde.epsilon)
+    rtol = atol = 1e-7                        # well below the bar: see test_adaptive_dopri5_driver_matches_oracle
+    TOL = 5e-5
+    sched = lambda tr: sm._schedule(tr, "ode")[:3]
+    if case == "ve_sample":
+        x = x * sm.sde.sigma_max
+        y, _, st = _walk(built_library, sm, net, MODE_STATE, -1.0, x, None, -1.0, -float(torch.tensor(eps, dtype=torch.float32)), rtol, atol, None)
+        ref = so.sample_ode_from_base((x / sm.sde.sigma_max).double(), None, "dopri5", None, atol, rtol)
+        assert st.done == 1 and st.n_accepted >= 3 and max_rel(y, ref, floor=ref.abs().max().item()) < TOL
+        host = adaptive.Dopri5(net.make_step(sched, -1.0, MODE_STATE, "cpu", launcher=_cpu_launcher(net, MODE_STATE)), False, rtol, atol, None)
+        yh, _ = host.integrate(-1.0, -float(torch.tensor(eps, dtype=torch.float32)), x, None)
+    else:
+        mode = MODE_HUTCH if case == "vp_hutch" else MODE_EXACT
+        e = torch.sign(torch.randn(B, meta["D"])) if mode == MODE_HUTCH else None
+        t0 = float(torch.tensor(eps, dtype=torch.float32))
+        y, lp, st = _walk(built_library, sm, net, mode, 1.0, x, torch.zeros(B), t0, 1.0, rtol, atol, {"min_step": 1e-9}, cond, e)
+        xT, dlp = so.solve_odes_forward(x.double(), None if cond is None else cond.double(), "dopri5", {"min_step": 1e-9},
+                                        "hutch" if mode == MODE_HUTCH else "exact", None if e is None else e.double(), atol, rtol)
+        assert st.done == 1 and st.n_accepted >= 3
+        assert max_rel(y, xT, floor=xT.abs().max().item()) < TOL and max_rel(lp[:, None], dlp, floor=1.0) < TOL
+        host = adaptive.Dopri5(net.make_step(sched, 1.0, mode, "cpu", cond=cond, probe=e, launcher=_cpu_launcher(net, mode, cond, e)),
+                               True, rtol, atol, {"min_step": 1e-9})
+        yh, _ = host.integrate(t0, 1.0, x, torch.zeros(B))
+    # the host controller on the same emulated kernels: the same walk, give or take the accepts a last-bit difference of a
+    # transcendental flips over ~100 steps (the error ratio feeds back into the step size: DESIGN.md section 2.1)
+    slack = max(2, round(0.03 * host.n_attempts))
+    assert abs(host.n_attempts - st.n_attempts) <= slack and abs(host.n_accepted - st.n_accepted) <= slack
+    assert max_rel(y, yh, floor=yh.abs().max().item()) < TOL
