@@ -471,8 +471,9 @@ def streaming_helpers(device):
         ms_of(lambda: _native.stage_combine(out, x, ks[:4], [0.1, 0.2, 0.3, 0.4], 1.0)))
     rec("ff_stage_combine, 7 terms + x (36 B per element)", 36 * n,
         ms_of(lambda: _native.stage_combine(out, x, ks, [0.1 * (i + 1) for i in range(7)], 1.0)))
-    rec("ff_scaled_rms, error norm of an adaptive step + finiteness check of y1 (err, y0, y1: 12 B per element, one pass)", 12 * n,
-        ms_of(lambda: _native.scaled_rms([(ks[1], None, x, ks[0])], 1e-5, 1e-5, check=ks[0])))
+    rec("ff_scaled_rms, error norm of an adaptive step + finiteness check of y1 (err, y0, y1: 12 B per element, one pass; "
+        "the kernel alone, as the device-side controller runs it: no read-back)", 12 * n,
+        ms_of(lambda: _native.scaled_rms([(ks[1], None, x, ks[0])], 1e-5, 1e-5, check=ks[0], read=False)))
     rec("ff_normal_fill (4 B per element written; Philox4x32-10 + Box-Muller)", 4 * n,
         ms_of(lambda: _native.normal_fill(B, D, 1234, 0, device)))
     return rows

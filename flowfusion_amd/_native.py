@@ -338,10 +338,11 @@ def stage_combine(out: torch.Tensor, x: Optional[torch.Tensor], ks, coefs, x_coe
 _norm_ws = {}     # (device index, stream) -> (workspace, out) of ff_scaled_rms
 
 
-def scaled_rms(terms, atol: float, rtol: float, check: Optional[torch.Tensor] = None) -> List[float]:
+def scaled_rms(terms, atol: float, rtol: float, check: Optional[torch.Tensor] = None, read: bool = True):
     """ff_scaled_rms: ``terms`` = up to 3 tuples (num, sub or None, scale0, scale1 or None) of equal-sized fp32 device
-    tensors; returns [rms_0, .., rms_{n-1}, nonfinite(check)] as Python floats -- one launch, one read-back (this is
-    the single host synchronisation of an attempted adaptive step)."""
+    tensors; returns [rms_0, .., rms_{n-1}, nonfinite(check)] as Python floats -- one launch, one read-back (the single
+    host synchronisation of an attempted step under the host controller).  ``read=False`` returns the device tensor the
+    kernel wrote instead (no synchronisation; valid until the next call on this stream)."""
     dev = terms[0][0].device
     if dev.type != "cuda":
         raise RuntimeError("flowfusion_amd: ff_scaled_rms works on device memory (there is no CPU path)")
@@ -365,7 +366,7 @@ def scaled_rms(terms, atol: float, rtol: float, check: Optional[torch.Tensor] = 
     if rc != FF_OK:
         ws[:4].zero_()      # whatever happened to the launch, the arrival counter starts the next one from zero
         raise _err(rc, "ff_scaled_rms")
-    return out[: len(terms) + 1].tolist()
+    return out[: len(terms) + 1].tolist() if read else out[: len(terms) + 1]
 
 
 def norm_workspace(dev, stream: int):
