@@ -10,7 +10,7 @@ What is native (csrc/ff_mlp_ode.hpp through the C ABI in include/flowfusion_amd.
 ``ScoreModel.sample_ode_from_base``, ``solve_odes_forward`` / ``log_prob`` (Hutchinson probe or
 exact trace) and ``sample_sde``, for an ``MLP`` score network with SiLU activations and a
 fixed-grid ``method`` (``euler``, ``midpoint``, ``heun3``, ``rk4`` + ``options={"step_size": h}``) or
-the reference's default adaptive ``dopri5`` (one launch per attempted step, adaptive.py).
+the reference's default adaptive ``dopri5`` (step control on the device, device_adaptive.py; host controller: adaptive.py).
 Anything else on those methods (other adaptive solvers, Hutch++/XTrace, CPU tensors) raises: there is no
 eager/CPU fallback behind them.  The small pointwise members (``MLP.forward``, ``score``,
 ``ode_drift``, the SDE schedule functions) are ordinary torch code, used by training code and to
@@ -377,7 +377,7 @@ class ScoreModel(nn.Module):
 
     def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, **affine):
         """odeint(self, state, t_span, method=, atol=, rtol=, options=) on the fused kernels:
-        fixed-grid methods as one launch, ``dopri5`` as one launch per attempted step.  ``affine``
+        fixed-grid methods as one launch, the adaptive methods with the step control on the device.  ``affine``
         (in_shift / in_scale / out_scale / out_shift, the PopulationModel wrappers' pre- and post-processing)
         rides in the kernel's prologue / epilogue on fixed grids and is applied around the adaptive loop."""
         if not self._fusable():

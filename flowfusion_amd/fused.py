@@ -214,7 +214,7 @@ class FusedNet:
             self._tables[full] = hit
         return hit
 
-    # -- adaptive stepping: one launch per attempted step (flowfusion_amd/adaptive.py) -----------
+    # -- adaptive stepping under the HOST controller: one launch per attempted step (flowfusion_amd/adaptive.py) -----------
     def make_step(self, schedule, sign: float, mode: int, device, cond=None, probe=None, launcher=None):
         """Step function for ``adaptive.Dopri5``.  ``schedule(t_real fp32 [n]) -> (a, b, c1)`` supplies
         the time-dependent scalars and first-layer bias; ``sign`` = -1 for a decreasing span (solved

@@ -103,8 +103,8 @@ def resolve_method(method: str) -> Tableau:
         return FIXED_METHODS[method]
     if method in ADAPTIVE_METHODS:
         raise NotImplementedError(
-            f"method={method!r}: of torchdiffeq's adaptive solvers {NATIVE_ADAPTIVE} run natively (one launch per attempted "
-            "step); dopri8 needs 13 stage slots and the fused kernels keep 7 on chip.  Fixed grids: "
+            f"method={method!r}: of torchdiffeq's adaptive solvers {NATIVE_ADAPTIVE} run natively (step control on the "
+            "device); dopri8 needs 13 stage slots and the fused kernels keep 7 on chip.  Fixed grids: "
             f"{sorted(FIXED_METHODS)} with options={{'step_size': h}}.")
     raise ValueError(f"unknown ODE method {method!r}; supported: {sorted(FIXED_METHODS)}")
 

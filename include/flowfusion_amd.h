@@ -80,14 +80,14 @@ extern "C" {
  *                   bits) and a product is the sum of the six bf16 MFMAs whose parts' exponents sum to more than
  *                   2^-24 (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid, lo.hi), accumulated in fp32: fp32-class
  *                   accuracy (error ~1e-7 relative to sum |w||x|, like an fp32 dot product) at the bf16 matrix
- *                   rate.  SiLU networks up to 256 wide, dim <= 16, cond_dim <= 16; every mode, noise rows and the
- *                   adaptive-step fields of the launch arguments, jac_out excepted; see DESIGN.md section 3.2.
+ *                   rate.  SiLU networks of 1-4 hidden layers up to 256 wide, dim <= 16, cond_dim <= 16; state-only
+ *                   solves (FF_MODE_STATE: noise rows and the adaptive-step fields included); see DESIGN.md section 3.2.
  *   FF_PREC_BF16X2  opt-in: two bf16 parts by round-to-nearest (hi + mid = the operand to 16 significand bits) and
  *                   the three products hi.hi, hi.mid, mid.hi: operands rounded to 2^-17 relative (TF32 keeps 2^-11),
  *                   unbiased, fp32 accumulation; error of a 256-term layer ~4e-7 relative to sum |w||x| in the mean
- *                   (fp32: 2e-8) at half the MFMAs of FF_PREC_BF16X3.  Coverage of FF_PREC_BF16X3 plus states of up to
- *                   32 dimensions (those plans keep 4 stage slots on chip instead of FF_MAX_SLOTS: tables must not
- *                   name a slot >= 4). */
+ *                   (fp32: 2e-8) at half the MFMAs of FF_PREC_BF16X3.  Same networks, every mode (jac_out excepted)
+ *                   and, state-only, states of up to 32 dimensions (those plans keep 4 stage slots on chip instead of
+ *                   FF_MAX_SLOTS: tables must not name a slot >= 4). */
 #define FF_PREC_F32        0
 #define FF_PREC_BF16X3     1
 #define FF_PREC_BF16X2     2
