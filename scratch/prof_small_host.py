@@ -1,0 +1,18 @@
+"""Where the host time of a small default-argument call goes (B = 1000, notebook model): cProfile over 300 calls."""
+import cProfile, pstats, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flowfusion_amd.diffusion import MLP, VESDE, ScoreModel
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+nb = ScoreModel(MLP(2, 0, 8, [128] * 3), VESDE()).eval().to(dev)
+z = torch.randn(1000, 2, device=dev)
+for _ in range(20): nb.sample_ode_from_base(z)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(300): nb.sample_ode_from_base(z)
+torch.cuda.synchronize()
+print("ms per call", (time.perf_counter() - t0) / 300 * 1e3)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(300): nb.sample_ode_from_base(z)
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
