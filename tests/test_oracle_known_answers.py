@@ -113,3 +113,76 @@ def test_gaussian_sampling_transport():
     me, ve = so.moments(sde.epsilon.reshape(1))
     expect = me * mu + torch.sqrt(ve / v1) * (z - m1 * mu)
     torch.testing.assert_close(x, expect, rtol=1e-6, atol=1e-6)
+
+
+# ---- the embedded pairs' tableaux against an independent published source, and against their order conditions -----------
+def _order_residuals(c, A, b, order):
+    """Largest violation of the Runge-Kutta order conditions up to `order` (rooted trees up to 4 nodes spelled out, plus the
+    quadrature conditions sum_i b_i c_i^k = 1/(k+1) up to order-1) for nodes c, matrix A and weights b."""
+    import numpy as np
+    c, A, b = np.asarray(c, float), np.asarray(A, float), np.asarray(b, float)
+    res = [abs(b.sum() - 1.0)]
+    for k in range(1, order):
+        res.append(abs((b * c ** k).sum() - 1.0 / (k + 1)))
+    if order >= 3:
+        res.append(abs(b @ A @ c - 1.0 / 6))
+    if order >= 4:
+        res += [abs((b * c) @ A @ c - 1.0 / 8), abs(b @ A @ (c ** 2) - 1.0 / 12), abs(b @ A @ A @ c - 1.0 / 24)]
+    res.append(np.abs(A.sum(axis=1) - c).max())          # row sums
+    return max(res)
+
+
+def _as_matrix(alpha, beta, stages):
+    import numpy as np
+    c = np.zeros(stages)
+    A = np.zeros((stages, stages))
+    for i, (al, row) in enumerate(zip(alpha, beta)):
+        c[i + 1] = al
+        A[i + 1, : len(row)] = row
+    return c, A
+
+
+def test_embedded_tableaux_against_scipy_and_order_conditions():
+    """torchdiffeq is not available offline (the steppers' parity is unpinned), but the NUMBERS of two of
+    its pairs are published elsewhere in this image: scipy's RK45 is Dormand-Prince 5(4) (same nodes, matrix and fifth-order
+    weights; its error estimate uses Dormand-Prince's own fourth-order weights where torchdiffeq uses Shampine's, so c_error is
+    not comparable) and RK23 is Bogacki-Shampine 3(2) (everything comparable, error up to sign).  What scipy cannot pin --
+    torchdiffeq's c_error of dopri5, fehlberg2, adaptive_heun -- must at least be what it claims to be: c_sol of the stated
+    order, c_sol - c_error an embedded solution one order lower."""
+    import numpy as np
+    from scipy.integrate._ivp import rk
+    from flowfusion_amd import adaptive, solvers
+    from oracle import flowfusion_oracle as O
+    # product, oracle and the fixed-step Dormand-Prince table all carry the same numbers
+    assert list(adaptive.ALPHA) == list(O._DP5_ALPHA) and [list(r) for r in adaptive.BETA] == [list(r) for r in O._DP5_BETA]
+    assert list(adaptive.C_SOL) == list(O._DP5_C_SOL) and list(adaptive.C_ERROR) == list(O._DP5_C_ERR)
+    c, A = _as_matrix(adaptive.ALPHA, adaptive.BETA, 7)
+    np.testing.assert_allclose(c[:6], rk.RK45.C, rtol=0, atol=1e-16)
+    np.testing.assert_allclose(A[:6, :5], rk.RK45.A, rtol=0, atol=2e-16)
+    np.testing.assert_allclose(adaptive.C_SOL[:6], rk.RK45.B, rtol=0, atol=1e-16)
+    np.testing.assert_allclose(A[6, :6], rk.RK45.B, rtol=0, atol=1e-16)                      # first same as last
+    dp = solvers.DOPRI5_FIXED
+    np.testing.assert_allclose([0.0 if v is None else v for v in dp.c[:5]], rk.RK45.C[:5], atol=1e-16)
+    np.testing.assert_allclose(dp.b, rk.RK45.B, atol=1e-16)
+    bs = adaptive.TABLEAUX["bosh3"]
+    cb, Ab = _as_matrix(bs.alpha, bs.beta, 4)
+    np.testing.assert_allclose(cb[:3], rk.RK23.C, atol=1e-16)
+    np.testing.assert_allclose(Ab[:3, :3], rk.RK23.A, atol=1e-16)
+    np.testing.assert_allclose(bs.c_sol[:3], rk.RK23.B, atol=1e-16)
+    np.testing.assert_allclose(np.asarray(bs.c_error), -rk.RK23.E, atol=1e-16)                # error up to sign
+    # order conditions: c_sol of order p, c_sol - c_error of order p - 1 (the pair's `order` is p)
+    for name, tab in adaptive.TABLEAUX.items():
+        c, A = _as_matrix(tab.alpha, tab.beta, tab.stages)
+        hi = _order_residuals(c, A, tab.c_sol, min(tab.order, 4))
+        lo = _order_residuals(c, A, np.asarray(tab.c_sol) - np.asarray(tab.c_error), min(tab.order - 1, 4))
+        assert hi < 1e-15 and lo < 1e-15, (name, hi, lo)
+    # ... and for dopri5 the quadrature conditions up to the full orders 5 and 4 (bushy trees)
+    c, A = _as_matrix(adaptive.ALPHA, adaptive.BETA, 7)
+    for k in range(5):
+        assert abs((np.asarray(adaptive.C_SOL) * c ** k).sum() - 1 / (k + 1)) < 1e-15
+    for k in range(4):
+        assert abs(((np.asarray(adaptive.C_SOL) - np.asarray(adaptive.C_ERROR)) * c ** k).sum() - 1 / (k + 1)) < 1e-15
+    # dense output: torchdiffeq's c_mid reproduces y(t0 + dt/2) to fifth order for y' = y-like polynomials: weights sum to 1/2
+    assert abs(sum(adaptive.C_MID) - 0.5) < 1e-15
+    for k in range(1, 4):
+        assert abs((np.asarray(adaptive.C_MID) * c ** k).sum() - 0.5 ** (k + 1) / (k + 1)) < 1e-12, k
