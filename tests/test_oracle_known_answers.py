@@ -186,3 +186,22 @@ def test_embedded_tableaux_against_scipy_and_order_conditions():
     assert abs(sum(adaptive.C_MID) - 0.5) < 1e-15
     for k in range(1, 4):
         assert abs((np.asarray(adaptive.C_MID) * c ** k).sum() - 0.5 ** (k + 1) / (k + 1)) < 1e-12, k
+
+
+def test_fixed_grid_tableaux_satisfy_their_order_conditions():
+    """euler (1), midpoint (2), heun3 (3), rk4 = the 3/8 rule and rk4_classic (4), fixed-step Dormand-Prince (5: checked to
+    4 with all trees and to 5 on the quadrature conditions): the product's evaluation-row programs are built from these."""
+    import numpy as np
+    from flowfusion_amd import solvers
+    want = {"euler": 1, "midpoint": 2, "heun3": 3, "rk4": 4, "rk4_classic": 4, "dopri5_fixed": 5}
+    for name, tab in solvers.FIXED_METHODS.items():
+        S = tab.stages
+        c = np.array([1.0 if v is None else v for v in tab.c], float)
+        A = np.zeros((S, S))
+        for i, row in enumerate(tab.A):
+            A[i, : len(row)] = row
+        assert _order_residuals(c, A, tab.b, min(want[name], 4)) < 1e-15, name
+        for k in range(want[name]):
+            assert abs((np.asarray(tab.b) * c ** k).sum() - 1 / (k + 1)) < 1e-15, (name, k)
+    # the 3/8 rule is what torchdiffeq calls rk4 (rk4_alt_step_func): its nodes are thirds, not halves
+    assert list(solvers.RK4_38.c[:3]) == [0.0, 1 / 3, 2 / 3] and list(solvers.RK4_38.b) == [0.125, 0.375, 0.375, 0.125]
