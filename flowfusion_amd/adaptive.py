@@ -71,6 +71,55 @@ TABLEAUX = {
 }
 
 
+# Dormand-Prince 8(7), 13 stages + the first-same-as-last stage (torchdiffeq dopri8.py: Prince & Dormand's RK8(7)13M).
+# torchdiffeq is not available offline; the nodes, matrix, eighth-order weights and seventh-order embedded weights below are
+# restated from memory of that file and VERIFIED, not trusted: row sums, every rooted-tree condition up to order 4 and the
+# quadrature conditions sum b_i c_i^k = 1/(k+1) hold to 1e-15 for k <= 7 (b8) and k <= 6 (b7, which must and does fail
+# k = 7 by 1e-4), and the eighth-order solution converges with order 8 (tests/test_oracle_known_answers.py).  A wrong digit
+# anywhere breaks one of them at the 1e-10 level.
+_DP8_C = (1 / 18, 1 / 12, 1 / 8, 5 / 16, 3 / 8, 59 / 400, 93 / 200, 5490023248 / 9719169821, 13 / 20,
+          1201146811 / 1299019798, 1.0, 1.0)
+_DP8_B8 = (14005451 / 335480064, 0, 0, 0, 0, -59238493 / 1068277825, 181606767 / 758867731, 561292985 / 797845732,
+           -1041891430 / 1371343529, 760417239 / 1151165299, 118820643 / 751138087, -528747749 / 2220607170, 1 / 4)
+_DP8_B7 = (13451932 / 455176623, 0, 0, 0, 0, -808719846 / 976000145, 1757004468 / 5645159321, 656045339 / 265891186,
+           -3867574721 / 1518517206, 465885868 / 322736535, 53011238 / 667516719, 2 / 45, 0)
+_DP8_A = (
+    (1 / 18,),
+    (1 / 48, 1 / 16),
+    (1 / 32, 0, 3 / 32),
+    (5 / 16, 0, -75 / 64, 75 / 64),
+    (3 / 80, 0, 0, 3 / 16, 3 / 20),
+    (29443841 / 614563906, 0, 0, 77736538 / 692538347, -28693883 / 1125000000, 23124283 / 1800000000),
+    (16016141 / 946692911, 0, 0, 61564180 / 158732637, 22789713 / 633445777, 545815736 / 2771057229, -180193667 / 1043307555),
+    (39632708 / 573591083, 0, 0, -433636366 / 683701615, -421739975 / 2616292301, 100302831 / 723423059,
+     790204164 / 839813087, 800635310 / 3783071287),
+    (246121993 / 1340847787, 0, 0, -37695042795 / 15268766246, -309121744 / 1061227803, -12992083 / 490766935,
+     6005943493 / 2108947869, 393006217 / 1396673457, 123872331 / 1001029789),
+    (-1028468189 / 846180014, 0, 0, 8478235783 / 508512852, 1311729495 / 1432422823, -10304129995 / 1701304382,
+     -48777925059 / 3047939560, 15336726248 / 1032824649, -45442868181 / 3398467696, 3065993473 / 597172653),
+    (185892177 / 718116043, 0, 0, -3185094517 / 667107341, -477755414 / 1098053517, -703635378 / 230739211,
+     5731566787 / 1027545527, 5232866602 / 850066563, -4093664535 / 808688257, 3962137247 / 1805957418, 65686358 / 487910083),
+    (403863854 / 491063109, 0, 0, -5068492393 / 434740067, -411421997 / 543043805, 652783627 / 914296604,
+     11173962825 / 925320556, -13158990841 / 6184727034, 3936647629 / 1978049680, -160528059 / 685178525,
+     248638103 / 1413531060, 0),
+)
+# Dense-output midpoint y(t0 + dt/2) ~ y0 + dt sum_i m_i k_i.  torchdiffeq evaluates a seventh-order continuous extension
+# at 1/2 there (long decimal coefficients that cannot be recalled or re-derived digit for digit); these weights are this
+# build's own: the minimum-norm solution, on the stages the eighth-order weights use, of ALL rooted-tree conditions up to
+# order 5 at theta = 1/2 plus the quadrature conditions up to k = 7 (residual 2e-16; measured midpoint error ~ dt^6).
+# torchdiffeq only uses the midpoint inside its quartic Hermite fit of the LAST step (error O(dt^5) whatever the midpoint's
+# order), so the difference is far below any tolerance the solver is run at -- but it is a difference, and it is stated.
+_DP8_MID = (0.04303473960045479, 0.0, 0.0, 0.0, 0.0, 0.10243459611345074, 0.22994756530151478, 0.2305207916012828,
+            -0.17844101414677382, 0.07627042306944881, -0.0061595447067761405, 0.0007974810543300986,
+            0.000797481057637911, 0.0007974810554298717)
+
+# pairs with more stages than the fused kernels keep on chip (FF_MAX_SLOTS = 7): stepped stage by stage (HostSteppedPair)
+WIDE_TABLEAUX = {
+    "dopri8": EmbeddedTableau("dopri8", 8, _DP8_C + (1.0,), _DP8_A + (_DP8_B8,), _DP8_B8 + (0.0,),
+                              tuple(a - b for a, b in zip(_DP8_B8, _DP8_B7)) + (0.0,), _DP8_MID),
+}
+
+
 def _f32(v) -> torch.Tensor:
     return torch.as_tensor(v, dtype=torch.float32)
 
@@ -105,13 +154,30 @@ class Dopri5:
         ``conditional`` of ConditionalODEFlow, flow.py:779-796, 855-881).  Under the mixed norm they can only
         matter where the state itself is measured -- d0 of the initial step; their derivative and error
         estimate are identically zero."""
-        opts = dict(options or {})
         if method not in TABLEAUX:
-            raise NotImplementedError(f"adaptive method {method!r}: supported {sorted(TABLEAUX)} (dopri8 needs 13 stage "
-                                      "slots; the fused kernels keep 7 on chip)")
+            raise NotImplementedError(f"adaptive method {method!r}: {sorted(TABLEAUX)} run one launch per attempted step; "
+                                      f"{sorted(WIDE_TABLEAUX)} have more stages than the 7 slots the fused kernels keep on chip "
+                                      "and take adaptive.HostSteppedPair (adaptive.make_solver picks)")
         self.tab = TABLEAUX[method]
-        self.norm_only = [c for c in norm_only if c is not None and c.numel() > 0]
         self.step = step
+        self._init_control(has_lp, rtol, atol, options, norm_only)
+        # the tableau as fp32 tensors, once per solve (an attempt then costs a handful of host tensor ops instead of ~40)
+        S = self.tab.stages
+        self._alpha = _f32(self.tab.alpha)
+        self._alpha_is_one = torch.tensor([a == 1.0 for a in self.tab.alpha])
+        self._beta8 = torch.zeros(S - 1, 8)
+        for i, beta in enumerate(self.tab.beta):
+            self._beta8[i, : len(beta)] = _f32(beta)
+        pad = lambda c: torch.cat([_f32(c), torch.zeros(8 - S)])
+        self._c_sol8, self._c_mid8, self._c_err8 = pad(self.tab.c_sol), pad(self.tab.c_mid), pad(self.tab.c_error)
+        self._last_stage = _onehot(S - 1)
+        self._stage_slots = torch.arange(1, S, dtype=torch.int32)
+
+    def _init_control(self, has_lp, rtol, atol, options, norm_only):
+        """Tolerances and torchdiffeq's step-control options (shared by the one-launch-per-attempt and the stage-by-stage
+        drivers)."""
+        opts = dict(options or {})
+        self.norm_only = [c for c in norm_only if c is not None and c.numel() > 0]
         self.has_lp = has_lp
         self.rtol = float(rtol)
         self.atol = float(atol)
@@ -124,17 +190,6 @@ class Dopri5:
                 raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
         self.n_attempts = 0
         self.n_accepted = 0
-        # the tableau as fp32 tensors, once per solve (an attempt then costs a handful of host tensor ops instead of ~40)
-        S = self.tab.stages
-        self._alpha = _f32(self.tab.alpha)
-        self._alpha_is_one = torch.tensor([a == 1.0 for a in self.tab.alpha])
-        self._beta8 = torch.zeros(S - 1, 8)
-        for i, beta in enumerate(self.tab.beta):
-            self._beta8[i, : len(beta)] = _f32(beta)
-        pad = lambda c: torch.cat([_f32(c), torch.zeros(8 - S)])
-        self._c_sol8, self._c_mid8, self._c_err8 = pad(self.tab.c_sol), pad(self.tab.c_mid), pad(self.tab.c_error)
-        self._last_stage = _onehot(S - 1)
-        self._stage_slots = torch.arange(1, S, dtype=torch.int32)
 
     # -- single launches ----------------------------------------------------------------------
     def _deriv(self, t, y, lp, k1=None, kl1=None, h=None):
@@ -312,3 +367,85 @@ class Dopri5:
             lp0, lp1, lpmid, fl0, fl1 = lps
             lp = self._fit_eval(lp0, lp1, lpmid, fl0, fl1, dt, x)
         return y, lp
+
+
+def _lincomb(x, ks, coefs, like, x_coef=1.0):
+    """x_coef * x + sum_i coefs[i] * ks[i] over any number of terms: ff_stage_combine passes of up to 7 terms on the GPU
+    (terms with a zero coefficient are never read); plain torch on CPU tensors (the tests' kernel-semantics emulator)."""
+    terms = [(k, float(c)) for k, c in zip(ks, coefs) if k is not None and float(c) != 0.0]
+    if not like.is_cuda:
+        out = torch.zeros_like(like) if x is None or x_coef == 0.0 else x_coef * x
+        for k, c in terms:
+            out = out + c * k
+        return out
+    from . import _native
+    out = torch.empty_like(like)
+    if not terms:
+        return _native.stage_combine(out, x, [], [], x_coef)
+    first = True
+    for i in range(0, len(terms), 7):
+        part = terms[i:i + 7]
+        _native.stage_combine(out, x if first else out, [k for k, _ in part], [c for _, c in part], x_coef if first else 1.0)
+        first = False
+    return out
+
+
+class HostSteppedPair(Dopri5):
+    """torchdiffeq's embedded pairs with more stages than the fused kernels keep on chip -- ``dopri8``: 13 stages and the
+    first-same-as-last one against FF_MAX_SLOTS = 7 stage slots and 8 coefficient words per evaluation row.  The
+    reference passes ``method=`` straight to ``odeint`` (diffusion.py:631-639, 744-752; flow.py:371-382), so the method is
+    reachable; nothing in the reference uses it.  Same step control as ``Dopri5`` (inherited: initial step, mixed RMS
+    norm, accept / reject, step-size law, dense output at the end); an attempted step is walked stage by stage on the
+    host: every stage ONE right-hand-side evaluation -- a fused single-row launch of the network with its divergence, or
+    the user's module -- and every stage input / solution / midpoint / error combination ``ff_stage_combine`` passes
+    over the state.  13 + 1 evaluations per attempt whatever the driver, so at solver-sized batches the launches cost
+    nothing against the evaluations; at notebook sizes it is launch-bound (~40 launches per attempt)."""
+
+    def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None,
+                 norm_only=(), method: str = "dopri8"):
+        if method not in WIDE_TABLEAUX:
+            raise NotImplementedError(f"stage-by-stage stepping is for {sorted(WIDE_TABLEAUX)}; {method!r} runs on Dopri5")
+        self.tab = WIDE_TABLEAUX[method]
+        self.step = step
+        self._init_control(has_lp, rtol, atol, options, norm_only)
+        self._slot0 = torch.zeros(1, dtype=torch.int32)
+        self._cin0 = torch.zeros(1, 8)
+        self._tail0 = torch.stack([_onehot(0), torch.zeros(8), torch.zeros(8), torch.zeros(8)])
+
+    def _rhs(self, t32: torch.Tensor, y, lp):
+        """Solver-time derivative at fp32 time ``t32`` ([1] tensor): one evaluation row, slot 0, returned as aux_0."""
+        aux, aux_lp = self.step(y, None, lp, None, t32, self._cin0, self._slot0, self._tail0, 0, 1)
+        return aux[0], (aux_lp[0] if self.has_lp else None)
+
+    def _deriv(self, t, y, lp, k1=None, kl1=None, h=None):
+        yi = y if k1 is None else _lincomb(y, [k1], [float(_f32(h))], y)
+        return self._rhs(_f32([t]), yi, lp)
+
+    def _attempt(self, t0, dt, t1, y, lp, f0, fl0):
+        tab = self.tab
+        t0f, dtf, t1f = _f32(t0), _f32(dt), _f32(t1)              # time enters the stages in the state dtype
+        ks, kl = [f0], [fl0]
+        for alpha, beta in zip(tab.alpha, tab.beta):
+            ti = t1f if alpha == 1.0 else t0f + _f32(alpha) * dtf
+            yi = _lincomb(y, ks, [float(_f32(b) * dtf) for b in beta], y)
+            f, fl = self._rhs(ti.reshape(1), yi, lp)
+            ks.append(f)
+            kl.append(fl)
+        scaled = lambda c: [float(_f32(v) * dtf) for v in c]
+        aux = [_lincomb(y, ks, scaled(tab.c_sol), y), ks[-1], _lincomb(y, ks, scaled(tab.c_mid), y),
+               _lincomb(None, ks, scaled(tab.c_error), y, 0.0)]
+        aux_lp = None
+        if self.has_lp:
+            aux_lp = [_lincomb(lp, kl, scaled(tab.c_sol), lp), kl[-1], _lincomb(lp, kl, scaled(tab.c_mid), lp),
+                      _lincomb(None, kl, scaled(tab.c_error), lp, 0.0)]
+        return aux, aux_lp
+
+
+def make_solver(step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None, norm_only=(),
+                method: str = "dopri5") -> Dopri5:
+    """The adaptive driver for ``method``: one launch per attempted step (``Dopri5``) for the pairs whose stages fit the
+    fused kernels' slots, stage by stage (``HostSteppedPair``) for ``dopri8``.  ``step`` has the contract of
+    ``FusedNet.make_step`` / ``generic.ModuleStepper.make_step`` / ``host_stepper.RowStepper.make_step`` either way."""
+    if method in WIDE_TABLEAUX:
+        return HostSteppedPair(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method)
+    return Dopri5(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method)

@@ -66,8 +66,8 @@ def build_config(spec: ScheduleSpec, sign: float, method: str, rtol: float, atol
     """``ff_adapt_config`` for an embedded pair of ``adaptive.TABLEAUX``; option handling as ``adaptive.Dopri5``.
     ``keep`` collects the tensors whose device pointers the struct carries."""
     if method not in adaptive.TABLEAUX:
-        raise NotImplementedError(f"adaptive method {method!r}: supported {sorted(adaptive.TABLEAUX)} (dopri8 needs 13 stage "
-                                  "slots; the fused kernels keep 7 on chip)")
+        raise NotImplementedError(f"adaptive method {method!r}: the device controller runs {sorted(adaptive.TABLEAUX)}; dopri8 (13 "
+                                  "stages, 7 slots on chip) is stepped stage by stage by adaptive.HostSteppedPair")
     tab = adaptive.TABLEAUX[method]
     opts = dict(options or {})
     c = _native.AdaptConfig()

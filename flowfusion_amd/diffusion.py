@@ -383,12 +383,12 @@ class ScoreModel(nn.Module):
         if not self._fusable():
             return self._solve_generic(x, t_span, method, options, mode, atol, rtol, affine)
         net = self._net()
-        if method in solvers.NATIVE_ADAPTIVE:
+        if method in solvers.ALL_ADAPTIVE:
             if affine.get("in_shift") is not None:
                 x = (x - affine["in_shift"]) / affine["in_scale"]
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
-            spec = self._device_schedule(x.device) if x.is_cuda else None
+            spec = self._device_schedule(x.device) if (x.is_cuda and method in solvers.NATIVE_ADAPTIVE) else None
             if device_adaptive.supported(spec, x, net, mode):
                 # the whole loop on the device: attempts, error norms, step control, the next attempt's table rows
                 y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]),
@@ -400,7 +400,7 @@ class ScoreModel(nn.Module):
             host = self._schedule_inputs()
             sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             step = net.make_step(sched, sign, mode, x.device, cond=cond, probe=probe)
-            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, method=method)
+            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, method=method)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
@@ -667,10 +667,10 @@ class ScoreModel(nn.Module):
         x = x0.detach().to(torch.float32).contiguous()
         stepper = host_stepper.RowStepper(net, x.device, conditional, lambda A: self._estimate_divergence(A, x))
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
-        if method in solvers.NATIVE_ADAPTIVE:
+        if method in solvers.ALL_ADAPTIVE:
             host = self._schedule_inputs()
             sched = lambda tr: self._schedule(tr, "ode", host)[:3]
-            solver = adaptive.Dopri5(stepper.make_step(sched, 1.0), True, rtol, atol, options, method=method)
+            solver = adaptive.make_solver(stepper.make_step(sched, 1.0), True, rtol, atol, options, method=method)
             y, lp = solver.integrate(float(t_span[0]), float(t_span[1]), x, torch.zeros(B, device=x.device))
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
         else:

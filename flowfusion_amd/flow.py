@@ -122,7 +122,7 @@ class _FlowBase(nn.Module):
         if not self._fusable():
             return self._solve_generic(x, t_span, method, options, mode, atol, rtol, cond, probe, raw_cond, affine)
         net = self._net()
-        if method in solvers.NATIVE_ADAPTIVE:
+        if method in solvers.ALL_ADAPTIVE:
             if any(v is not None for v in affine.values()):
                 raise AssertionError("affine epilogues are applied by the caller on the adaptive path")
             t = t_span.double()
@@ -130,7 +130,7 @@ class _FlowBase(nn.Module):
             # the reference keeps the raw conditional in the solver state (flow.py:779-796, 855-881)
             extra = () if raw_cond is None else (raw_cond.detach().to(x.device, torch.float32),)
             spec = None
-            if x.is_cuda:
+            if x.is_cuda and method in solvers.NATIVE_ADAPTIVE:
                 D = self.target_dimension
                 w0t, b0 = net.time_columns(x.device, D, D + 1)
                 spec = device_adaptive.ScheduleSpec(_native.SCHED_FLOW, (0.0, 0.0, 0.0), True, None, 0.0, w0t, b0)
@@ -142,7 +142,7 @@ class _FlowBase(nn.Module):
                 return y, lp
             first = net.first_layer_cpu()
             step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
-            solver = adaptive.Dopri5(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method)
+            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
@@ -161,7 +161,7 @@ class _FlowBase(nn.Module):
             raise NotImplementedError("gradients through the fused solve are not available; detach the input")
         method = _DEFAULT_SAMPLE_METHOD if method is None else method
         t_span = torch.tensor([1.0, 0.0], dtype=torch.float32)
-        if method in solvers.NATIVE_ADAPTIVE:
+        if method in solvers.ALL_ADAPTIVE:
             x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional, raw_cond=raw_cond)
             return x * self.target_scale + self.target_shift
         x, _ = self._solve(xT, t_span, method, options, MODE_STATE, atol, rtol, cond=conditional,

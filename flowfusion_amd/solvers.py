@@ -95,18 +95,21 @@ DOPRI5_FIXED = Tableau(
 
 FIXED_METHODS = {t.name: t for t in (EULER, MIDPOINT, HEUN3, RK4_38, RK4_CLASSIC, DOPRI5_FIXED)}
 ADAPTIVE_METHODS = ("dopri5", "dopri8", "bosh3", "fehlberg2", "adaptive_heun")
-NATIVE_ADAPTIVE = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")     # adaptive.TABLEAUX (dopri8: 13 stages > 7 slots)
+NATIVE_ADAPTIVE = ("dopri5", "bosh3", "fehlberg2", "adaptive_heun")     # adaptive.TABLEAUX: one fused launch per attempted step
+HOST_STEPPED_ADAPTIVE = ("dopri8",)    # adaptive.WIDE_TABLEAUX: 13 stages > 7 slots, one fused launch per STAGE
+ALL_ADAPTIVE = NATIVE_ADAPTIVE + HOST_STEPPED_ADAPTIVE
 
 
 def resolve_method(method: str) -> Tableau:
     if method in FIXED_METHODS:
         return FIXED_METHODS[method]
     if method in ADAPTIVE_METHODS:
+        raise NotImplementedError(f"method={method!r} is adaptive: no fixed-grid tableau (the front ends route it to the adaptive drivers)")
+    if method in ("explicit_adams", "implicit_adams", "fixed_adams", "scipy_solver"):
         raise NotImplementedError(
-            f"method={method!r}: of torchdiffeq's adaptive solvers {NATIVE_ADAPTIVE} run natively (step control on the "
-            "device); dopri8 needs 13 stage slots and the fused kernels keep 7 on chip.  Fixed grids: "
-            f"{sorted(FIXED_METHODS)} with options={{'step_size': h}}.")
-    raise ValueError(f"unknown ODE method {method!r}; supported: {sorted(FIXED_METHODS)}")
+            f"method={method!r}: torchdiffeq's multistep / scipy solvers are not built (adaptive: {ALL_ADAPTIVE}; fixed grids: "
+            f"{sorted(FIXED_METHODS)} with options={{'step_size': h}})")
+    raise ValueError(f"unknown ODE method {method!r}; supported: {sorted(FIXED_METHODS)} and {ALL_ADAPTIVE}")
 
 
 def fixed_grid(t: torch.Tensor, step_size: Optional[float]) -> torch.Tensor:

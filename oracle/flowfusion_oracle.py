@@ -482,6 +482,46 @@ _ADAPTIVE_TABLEAUX = {
 }
 
 
+# Dormand-Prince 8(7) (torchdiffeq dopri8.py: Prince & Dormand RK8(7)13M, 13 stages + the first-same-as-last one).  Restated
+# from memory like the rest of the stepper -- but checkable, and checked (tests/test_oracle_known_answers.py): order conditions of
+# the eighth-order weights b8 and of the embedded seventh-order weights b7, row sums, observed convergence order 8.  The
+# dense-output midpoint weights are this restatement's own (torchdiffeq's come from a continuous extension whose decimal
+# coefficients are not available offline): they satisfy every order condition up to 5 at theta = 1/2.
+_DP8_NODES = [1 / 18, 1 / 12, 1 / 8, 5 / 16, 3 / 8, 59 / 400, 93 / 200, 5490023248 / 9719169821, 13 / 20,
+              1201146811 / 1299019798, 1.0, 1.0]
+_DP8_MATRIX = [
+    [1 / 18],
+    [1 / 48, 1 / 16],
+    [1 / 32, 0, 3 / 32],
+    [5 / 16, 0, -75 / 64, 75 / 64],
+    [3 / 80, 0, 0, 3 / 16, 3 / 20],
+    [29443841 / 614563906, 0, 0, 77736538 / 692538347, -28693883 / 1125000000, 23124283 / 1800000000],
+    [16016141 / 946692911, 0, 0, 61564180 / 158732637, 22789713 / 633445777, 545815736 / 2771057229,
+     -180193667 / 1043307555],
+    [39632708 / 573591083, 0, 0, -433636366 / 683701615, -421739975 / 2616292301, 100302831 / 723423059,
+     790204164 / 839813087, 800635310 / 3783071287],
+    [246121993 / 1340847787, 0, 0, -37695042795 / 15268766246, -309121744 / 1061227803, -12992083 / 490766935,
+     6005943493 / 2108947869, 393006217 / 1396673457, 123872331 / 1001029789],
+    [-1028468189 / 846180014, 0, 0, 8478235783 / 508512852, 1311729495 / 1432422823, -10304129995 / 1701304382,
+     -48777925059 / 3047939560, 15336726248 / 1032824649, -45442868181 / 3398467696, 3065993473 / 597172653],
+    [185892177 / 718116043, 0, 0, -3185094517 / 667107341, -477755414 / 1098053517, -703635378 / 230739211,
+     5731566787 / 1027545527, 5232866602 / 850066563, -4093664535 / 808688257, 3962137247 / 1805957418,
+     65686358 / 487910083],
+    [403863854 / 491063109, 0, 0, -5068492393 / 434740067, -411421997 / 543043805, 652783627 / 914296604,
+     11173962825 / 925320556, -13158990841 / 6184727034, 3936647629 / 1978049680, -160528059 / 685178525,
+     248638103 / 1413531060, 0],
+]
+_DP8_W8 = [14005451 / 335480064, 0, 0, 0, 0, -59238493 / 1068277825, 181606767 / 758867731, 561292985 / 797845732,
+           -1041891430 / 1371343529, 760417239 / 1151165299, 118820643 / 751138087, -528747749 / 2220607170, 1 / 4]
+_DP8_W7 = [13451932 / 455176623, 0, 0, 0, 0, -808719846 / 976000145, 1757004468 / 5645159321, 656045339 / 265891186,
+           -3867574721 / 1518517206, 465885868 / 322736535, 53011238 / 667516719, 2 / 45, 0]
+_DP8_MIDPOINT = [0.04303473960045479, 0.0, 0.0, 0.0, 0.0, 0.10243459611345074, 0.22994756530151478, 0.2305207916012828,
+                 -0.17844101414677382, 0.07627042306944881, -0.0061595447067761405, 0.0007974810543300986,
+                 0.000797481057637911, 0.0007974810554298717]
+_ADAPTIVE_TABLEAUX["dopri8"] = (8, _DP8_NODES + [1.0], _DP8_MATRIX + [_DP8_W8], _DP8_W8 + [0.0],
+                                [a - b for a, b in zip(_DP8_W8, _DP8_W7)] + [0.0], _DP8_MIDPOINT)
+
+
 # attempts / accepted steps of the latest adaptive solve (kept up to date while it runs, so a solve that ends in
 # torchdiffeq's "underflow in dt" assertion still says how far it got)
 last_adaptive_stats = {"attempts": 0, "accepted": 0}

@@ -189,8 +189,8 @@ def test_options_and_assertions_match_the_host_controller(monkeypatch):
         return None, None
     (ma, sa), (mb, sb) = _both(monkeypatch, capped)
     assert ma == mb == "max_num_steps exceeded (4>=4)" and _same_counts(sa, sb) and sa["attempts"] == 4
-    with pytest.raises(NotImplementedError, match="dopri8"):
-        sm.sample_ode_from_base(base.to(DEV), method="dopri8")
+    with pytest.raises(NotImplementedError, match="multistep"):
+        sm.sample_ode_from_base(base.to(DEV), method="implicit_adams")
     with pytest.raises(NotImplementedError, match="step_t"):
         sm.sample_ode_from_base(base.to(DEV), options={"step_t": torch.tensor([0.5])})
 

@@ -316,8 +316,42 @@ def test_other_adaptive_methods_run_natively(method):
     lp = sm.log_prob(x0.to(DEV), method=method, atol=1e-5, rtol=1e-5)
     ref = so32.log_prob(x0, None, method, {"min_step": 1e-6}, "hutch", sm.e.cpu(), 1e-5, 1e-5)
     assert _logp_err(lp, ref) < 5e-4
-    with pytest.raises(NotImplementedError, match="dopri8"):
-        sm.sample_ode_from_base(base.to(DEV), method="dopri8")
+
+
+def test_dopri8_runs_stage_by_stage():
+    """`method="dopri8"` reaches torchdiffeq through the reference's pass-through (diffusion.py:631-639, flow.py:371-382).
+    13 stages + FSAL do not fit the fused kernels' 7 stage slots, so an attempted step is walked stage by stage (one fused
+    single-row launch per stage, ff_stage_combine for the algebra: adaptive.HostSteppedPair) under the same step control:
+    sampling, Hutchinson and exact-trace log-density, a flow, and any other `model=` module, against the oracle's
+    restatement of the pair (tableau verified by its order conditions, tests/test_oracle_known_answers.py)."""
+    from flowfusion_amd import flow as Fm
+    from oracle import flowfusion_oracle as O
+    sm, so32, _ = _seeded_score_model(4, 2, [128, 128], "VESDE", False, 191)
+    torch.manual_seed(8)
+    base, cond = torch.randn(200, 4), torch.randn(200, 2)
+    x, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV), method="dopri8", atol=1e-5, rtol=1e-5)
+    st = dict(sm.last_solver_stats)
+    assert st["accepted"] >= 3 and "chunks" not in st                       # the host-stepped driver, not the device controller
+    assert _state_err(x, so32.sample_ode_from_base(base, cond, "dopri8", None, 1e-5, 1e-5)) < ADAPT_TOL
+    x5, _ = sm.sample_ode_from_base(base.to(DEV), conditional=cond.to(DEV), atol=1e-6, rtol=1e-6)      # dopri5
+    assert _state_err(x, x5.cpu()) < ADAPT_TOL and sm.last_solver_stats["attempts"] > st["attempts"]    # higher order, fewer steps
+    x0 = torch.randn(48, 4) * 0.5
+    for hutch in (True, False):
+        sm.hutch = hutch
+        torch.manual_seed(5)
+        lp = sm.log_prob(x0.to(DEV), conditional=cond[:48].to(DEV), method="dopri8", atol=1e-5, rtol=1e-5)
+        ref = so32.log_prob(x0, cond[:48], "dopri8", {"min_step": 1e-6}, "hutch" if hutch else "exact", sm.e.cpu() if hutch else None,
+                            1e-5, 1e-5)
+        assert _logp_err(lp, ref) < ADAPT_TOL, hutch
+    sm.hutch = False
+    torch.manual_seed(31)
+    f = Fm.ODEFlow(3, [64, 64]).eval()
+    fo = O.FlowOracle(O.flow_params_from_state_dict({k: v.detach().clone() for k, v in f.state_dict().items()}))
+    f = f.to(DEV)
+    xT = torch.randn(100, 3)
+    assert _state_err(f.sample(xT.to(DEV), method="dopri8", atol=1e-6, rtol=1e-6), fo.sample(xT, None, "dopri8", None, 1e-6, 1e-6)) < ADAPT_TOL
+    lpf = f.log_prob(xT.to(DEV) * 0.7, method="dopri8")
+    assert _logp_err(lpf, fo.log_prob(xT * 0.7, None, "dopri8", None)) < ADAPT_TOL
 
 
 # ---- bench.py's N > 1 branch ---------------------------------------------------------------------------------------

@@ -93,6 +93,10 @@ def test_gaussian_density_and_transport_through_the_gpu_path(sde_name, kw):
     x, _ = sm.sample_ode_from_base(base, atol=1e-6, rtol=1e-6)                           # dopri5 (reference default method)
     assert sm.last_solver_stats["accepted"] >= 3
     assert (x - expect).abs().max().item() < 2e-3 * max(1.0, float(expect.abs().max()))
+    # dopri8 around the module (stage-by-stage driver): a closed-form transport map does not care who restated the tableau
+    x8, _ = sm.sample_ode_from_base(base, atol=1e-6, rtol=1e-6, method="dopri8")
+    assert sm.last_solver_stats["accepted"] >= 2
+    assert (x8 - expect).abs().max().item() < 2e-3 * max(1.0, float(expect.abs().max()))
     # Hutchinson and the default log_prob run too (adaptive, exact trace): same density within solver tolerance
     lp = sm.log_prob(x0[:32], atol=1e-6, rtol=1e-6)
     sm.hutch = True

@@ -81,8 +81,12 @@ def test_no_cpu_fallback(built_library):
         sm.sample_ode_from_base(torch.randn(8, 4), method="rk4", options={"step_size": 0.1})
     with pytest.raises(RuntimeError, match="GPU"):
         sm.sample_ode_from_base(torch.randn(8, 4))                # reference default method=dopri5 (adaptive)
-    with pytest.raises(NotImplementedError, match="adaptive"):
-        sm.sample_ode_from_base(torch.randn(8, 4), method="dopri8")
+    with pytest.raises(RuntimeError, match="GPU"):
+        sm.sample_ode_from_base(torch.randn(8, 4), method="dopri8")          # stage-by-stage driver: GPU only as well
+    with pytest.raises(NotImplementedError, match="multistep"):
+        sm.sample_ode_from_base(torch.randn(8, 4), method="explicit_adams")
+    with pytest.raises(ValueError, match="unknown ODE method"):
+        sm.sample_ode_from_base(torch.randn(8, 4), method="rk45")
     # outside the compiled envelope (an activation the kernels do not implement): said once, and still GPU only
     from flowfusion_amd.fused import FusedEnvelopeWarning
     mish = D.ScoreModel(D.MLP(4, 0, 8, [64], activation=torch.nn.Mish()), D.VPSDE()).eval()
@@ -469,8 +473,46 @@ def test_other_embedded_pairs_match_oracle(method, built_library):
     assert max_rel(y, xT, floor=xT.abs().max().item()) < 2e-4 and max_rel(lp[:, None], dlp, floor=1.0) < 2e-4
     x5, d5 = so.solve_odes_forward(x.double(), None, "dopri5", {"min_step": 1e-9}, "hutch", e.double(), 1e-9, 1e-9)
     assert max_rel(y, x5, floor=x5.abs().max().item()) < 1e-3 and max_rel(lp[:, None], d5, floor=1.0) < 1e-3
-    with pytest.raises(NotImplementedError, match="dopri8"):
-        adaptive.Dopri5(step, True, rtol, atol, None, method="dopri8")
+
+
+def test_dopri8_stage_by_stage_matches_oracle(built_library):
+    """torchdiffeq's dopri8 (13 stages + FSAL: more than the 7 stage slots / 8 row coefficients of the fused kernels) on the
+    stage-by-stage driver, adaptive.HostSteppedPair: every stage one emulated single-row launch, every combination a pass
+    over the state.  Sampling direction (reversed time) and Hutchinson log-density against the oracle's restatement of the
+    same pair, and convergence to the dopri5 answer; make_solver picks the driver by method."""
+    from flowfusion_amd import adaptive
+    torch.manual_seed(5)
+    meta = dict(D=3, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=False)
+    sm = D.ScoreModel(D.MLP(3, 0, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+    so = score_oracle(meta, {k: v.detach().clone() for k, v in sm.state_dict().items()}, torch.float64)
+    net = sm._net()
+    B = 5
+    x = torch.randn(B, 3) * 0.5
+    e = torch.sign(torch.randn(B, 3))
+    eps = float(torch.tensor(float(sm.sde.epsilon), dtype=torch.float32))
+    sched = lambda tr: sm._schedule(tr, "ode")[:3]
+    rtol = atol = 1e-7
+    step = net.make_step(sched, 1.0, MODE_HUTCH, "cpu", probe=e, launcher=_cpu_launcher(net, MODE_HUTCH, None, e))
+    solver = adaptive.make_solver(step, True, rtol, atol, {"min_step": 1e-9}, method="dopri8")
+    assert isinstance(solver, adaptive.HostSteppedPair) and solver.tab.stages == 14
+    assert type(adaptive.make_solver(step, True, rtol, atol, None, method="dopri5")) is adaptive.Dopri5
+    y, lp = solver.integrate(eps, 1.0, x, torch.zeros(B))
+    xT, dlp = so.solve_odes_forward(x.double(), None, "dopri8", {"min_step": 1e-9}, "hutch", e.double(), atol, rtol)
+    # (counts are not compared: at 1e-7 the fp32 rounding of the table rows is the size of the error estimate itself, and
+    # the float64 oracle takes fewer attempts over the same span)
+    assert solver.n_accepted >= 3 and O.last_adaptive_stats["accepted"] >= 3
+    assert max_rel(y, xT, floor=xT.abs().max().item()) < 5e-5 and max_rel(lp[:, None], dlp, floor=1.0) < 5e-5
+    x5, d5 = so.solve_odes_forward(x.double(), None, "dopri5", {"min_step": 1e-9}, "hutch", e.double(), 1e-9, 1e-9)
+    assert max_rel(y, x5, floor=x5.abs().max().item()) < 1e-4 and max_rel(lp[:, None], d5, floor=1.0) < 1e-4
+    # sampling: decreasing span, state only
+    z = torch.randn(B, 3) * sm.sde.sigma_max
+    step = net.make_step(sched, -1.0, MODE_STATE, "cpu", launcher=_cpu_launcher(net, MODE_STATE))
+    solver = adaptive.make_solver(step, False, rtol, atol, None, method="dopri8")
+    ys, _ = solver.integrate(-1.0, -eps, z, None)
+    ref = so.sample_ode_from_base((z / sm.sde.sigma_max).double(), None, "dopri8", None, atol, rtol)
+    assert max_rel(ys, ref, floor=ref.abs().max().item()) < 5e-5
+    with pytest.raises(NotImplementedError, match="HostSteppedPair"):
+        adaptive.Dopri5(step, False, rtol, atol, None, method="dopri8")
 
 
 def test_adaptive_nan_error_estimate_raises_like_torchdiffeq(built_library):

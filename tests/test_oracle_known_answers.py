@@ -205,3 +205,54 @@ def test_fixed_grid_tableaux_satisfy_their_order_conditions():
             assert abs((np.asarray(tab.b) * c ** k).sum() - 1 / (k + 1)) < 1e-15, (name, k)
     # the 3/8 rule is what torchdiffeq calls rk4 (rk4_alt_step_func): its nodes are thirds, not halves
     assert list(solvers.RK4_38.c[:3]) == [0.0, 1 / 3, 2 / 3] and list(solvers.RK4_38.b) == [0.125, 0.375, 0.375, 0.125]
+
+
+def test_dopri8_tableau_is_what_it_claims_to_be():
+    """Dormand-Prince 8(7)13M restated from memory of torchdiffeq's dopri8.py (not available offline) -- verified, not
+    trusted: row sums, all rooted trees to order 4, the quadrature conditions to k = 7 for the eighth-order weights and to
+    k = 6 for the embedded seventh-order ones (which must FAIL k = 7: they are not an eighth-order formula), observed
+    convergence order 8 / 7 on a nonlinear scalar ODE; the build's own midpoint weights satisfy every order condition up to 5
+    at theta = 1/2 and the quadrature conditions to k = 7.  Product and oracle carry the same numbers."""
+    import numpy as np
+    from flowfusion_amd import adaptive
+    from oracle import flowfusion_oracle as O
+    tab = adaptive.WIDE_TABLEAUX["dopri8"]
+    order, o_alpha, o_beta, o_sol, o_err, o_mid = O._ADAPTIVE_TABLEAUX["dopri8"]
+    assert (order, tab.order, tab.stages) == (8, 8, 14)
+    assert list(tab.alpha) == list(o_alpha) and [list(r) for r in tab.beta] == [list(r) for r in o_beta]
+    assert list(tab.c_sol) == list(o_sol) and list(tab.c_error) == list(o_err) and list(tab.c_mid) == list(o_mid)
+    c, A = _as_matrix(tab.alpha, tab.beta, 14)
+    b8 = np.asarray(tab.c_sol)
+    b7 = b8 - np.asarray(tab.c_error)
+    assert np.abs(A.sum(axis=1) - c).max() < 4e-15
+    assert _order_residuals(c, A, b8, 4) < 4e-15 and _order_residuals(c, A, b7, 4) < 4e-15
+    for k in range(8):
+        assert abs((b8 * c ** k).sum() - 1 / (k + 1)) < 1e-15, k
+    for k in range(7):
+        assert abs((b7 * c ** k).sum() - 1 / (k + 1)) < 1e-15, k
+    assert abs((b7 * c ** 7).sum() - 1 / 8) > 1e-5
+    assert np.array_equal(A[13, :13], b8[:13]) and b8[13] == 0.0                  # first same as last
+    # midpoint weights: rooted trees up to order 5 at theta = 1/2, quadrature to k = 7
+    m, th = np.asarray(tab.c_mid), 0.5
+    Ac, Ac2, Ac3 = A @ c, A @ c ** 2, A @ c ** 3
+    AAc = A @ Ac
+    trees = [(np.ones(14), th), (c, th ** 2 / 2), (c ** 2, th ** 3 / 3), (Ac, th ** 3 / 6), (c ** 3, th ** 4 / 4),
+             (c * Ac, th ** 4 / 8), (Ac2, th ** 4 / 12), (AAc, th ** 4 / 24), (c ** 4, th ** 5 / 5), (c ** 2 * Ac, th ** 5 / 10),
+             (c * Ac2, th ** 5 / 15), (c * AAc, th ** 5 / 30), (Ac * Ac, th ** 5 / 20), (Ac3, th ** 5 / 20),
+             (A @ (c * Ac), th ** 5 / 40), (A @ Ac2, th ** 5 / 60), (A @ AAc, th ** 5 / 120)]
+    trees += [(c ** k, th ** (k + 1) / (k + 1)) for k in (5, 6, 7)]
+    assert max(abs(m @ phi - want) for phi, want in trees) < 1e-15
+    # observed order on y' = cos(t) y (y = exp(sin t)): halving the step divides the error by ~2^8 (b8) and ~2^7 (b7)
+    f = lambda t, y: np.cos(t) * y
+
+    def solve(b, n):
+        y, t, h = 1.0, 0.0, 2.0 / n
+        for _ in range(n):
+            k = []
+            for i in range(13):
+                k.append(f(t + c[i] * h, y + h * sum(A[i, j] * k[j] for j in range(i))))
+            y, t = y + h * sum(b[i] * k[i] for i in range(13)), t + h
+        return abs(y - np.exp(np.sin(2.0)))
+    assert 7.5 < np.log2(solve(b8, 4) / solve(b8, 8)) < 8.8 and 7.5 < np.log2(solve(b8, 8) / solve(b8, 16)) < 8.8
+    assert 6.5 < np.log2(solve(b7, 4) / solve(b7, 8)) < 9.0
+    assert solve(b8, 16) < 1e-12
