@@ -185,7 +185,9 @@ class Dopri5:
         self.max_step = float(opts.pop("max_step", float("inf")))
         self.first_step = opts.pop("first_step", None)
         self.max_num_steps = int(opts.pop("max_num_steps", 2 ** 31 - 1))
-        for k in ("step_t", "jump_t", "norm", "dtype"):
+        if opts.get("dtype") not in (None, torch.float64):      # torchdiffeq's time dtype: float64 is its default and what runs here
+            raise NotImplementedError("adaptive option dtype: time is kept in float64 (torchdiffeq's default); other dtypes are not built")
+        for k in ("step_t", "jump_t", "norm"):
             if opts.get(k) is not None:
                 raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
         self.n_attempts = 0

@@ -85,7 +85,9 @@ def build_config(spec: ScheduleSpec, sign: float, method: str, rtol: float, atol
     first = opts.pop("first_step", None)
     c.first_step = float("nan") if first is None else float(first)
     c.max_num_steps = int(min(opts.pop("max_num_steps", 2 ** 31 - 1), 2 ** 31 - 1))
-    for k in ("step_t", "jump_t", "norm", "dtype"):
+    if opts.get("dtype") not in (None, torch.float64):          # torchdiffeq's time dtype: float64 is its default and what runs here
+        raise NotImplementedError("adaptive option dtype: time is kept in float64 (torchdiffeq's default); other dtypes are not built")
+    for k in ("step_t", "jump_t", "norm"):
         if opts.get(k) is not None:
             raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
     c.sched, c.no_sigma, c.sign = spec.sched, int(bool(spec.no_sigma)), float(sign)
