@@ -320,3 +320,47 @@ def test_cpu_walk_of_the_device_path_matches_oracle_and_host_controller(case, bu
     slack = max(2, round(0.03 * host.n_attempts))
     assert abs(host.n_attempts - st.n_attempts) <= slack and abs(host.n_accepted - st.n_accepted) <= slack
     assert max_rel(y, yh, floor=yh.abs().max().item()) < TOL
+
+
+def test_adaptive_entry_point_checks_its_arguments_before_any_hip_call(built_library):
+    """ff_mlp_ode_adaptive validates the plan / config / buffers on the host: bad arguments come back as FF_ERR_BADARG or
+    FF_ERR_UNSUPPORTED with nothing enqueued (no GPU needed to see that), an empty batch is FF_OK."""
+    lib = built_library
+    plan = _native.make_plan(4, 0, [64, 64], 0)
+    spec = device_adaptive.ScheduleSpec(_native.SCHED_FLOW, (0.0, 0.0, 0.0), True, None, 0.0, torch.zeros(64, 1), torch.zeros(64))
+    cfg, keep = _config(spec, 1.0, "dopri5")
+    buf = torch.zeros(4096)
+    b = _native.AdaptBuffers()
+    for name in ("y", "f0", "scratch_x", "etab", "out_y", "state", "norm_workspace"):
+        setattr(b, name, buf.data_ptr())
+    for j in range(4):
+        b.aux[j] = buf.data_ptr()
+    b.n_passes = 1
+    base = _native.OdeArgs()
+    base.wpack, base.mode, base.batch = buf.data_ptr(), 0, 0
+    call = lambda p=plan, a=base, c=cfg, bb=b, n=4: lib.ff_mlp_ode_adaptive(
+        ctypes.byref(p), ctypes.byref(a), ctypes.byref(c), ctypes.byref(bb), 0.0, 1.0, _native.ADAPT_START, n, None)
+    assert call() == _native.FF_OK                                         # empty batch: nothing to do
+    assert call(n=-1) == _native.FF_ERR_BADARG
+    class copy:          # ctypes structures holding pointers do not pickle-copy: clone the bytes
+        @staticmethod
+        def copy(st):
+            return type(st).from_buffer_copy(bytes(st))
+    bad = copy.copy(cfg); bad.n_stages = 1
+    assert call(c=bad) == _native.FF_ERR_BADARG
+    bad = copy.copy(cfg); bad.n_stages = 8
+    assert call(c=bad) == _native.FF_ERR_BADARG
+    bad = copy.copy(cfg); bad.sched = 7
+    assert call(c=bad) == _native.FF_ERR_BADARG
+    bad = copy.copy(cfg); bad.h_real = 65                                  # more first-layer rows than the plan's width
+    assert call(c=bad) == _native.FF_ERR_UNSUPPORTED
+    bad = copy.copy(cfg); bad.n_tcols = 2                                  # a flow has ONE time column
+    assert call(c=bad) == _native.FF_ERR_BADARG
+    bad = copy.copy(cfg); bad.sched = _native.SCHED_VE                     # a score schedule needs the embedding frequencies
+    assert call(c=bad) == _native.FF_ERR_BADARG
+    nb = copy.copy(b); nb.out_y = 0
+    assert call(bb=nb) == _native.FF_ERR_BADARG
+    nb = copy.copy(b); nb.n_passes = 9
+    assert call(bb=nb) == _native.FF_ERR_BADARG
+    hb = copy.copy(base); hb.mode = 1                                      # a divergence mode without its arrays
+    assert call(a=hb) == _native.FF_ERR_BADARG
