@@ -73,28 +73,29 @@ INSTANCES = [
     # Non-default activations (`activation=` of the reference constructors; its code, docs and notebooks only ever use
     # SiLU).  ACT = 9 chooses the function at run time (the chosen kind's stages run back to back behind a wave-uniform
     # switch): measured against the compiled-in variants (scratch/act_bench.py, profiles/r03/act_bench.txt) it costs
-    # 0-3 % for state-only solves at width 256 and is what the 512-wide kernels (a minute of compile time each) use;
-    # with tangent columns at width 256 it costs 16 % (the switch at every activation site spills 187 registers at two
-    # wavefronts per SIMD, so it runs one) and 9-11 % at width 128: those keep a compiled-in instantiation per
-    # activation (ACT = 1..8), without cooperative twins.
+    # 0-3 % for state-only solves at width 256, 9-14 % at width 128 and is what the 512-wide kernels (over a minute of
+    # compile time each) use; with tangent columns at width 256 it costs 16 % (the switch at every activation site spills
+    # 187 registers at two wavefronts per SIMD, so it would run one): THAT shape keeps a compiled-in instantiation per
+    # activation (ACT = 1..8), without cooperative twins.  The 128-wide ones were compiled in too until the clean build
+    # sat at 3 m 30-50 s of the 4 minutes allowed: 16 translation units for 10 % on networks nobody has shown to exist.
+    (32, 128, 16, 8, 0, 1, 8, 9), (32, 128, 16, 8, 1, 1, 8, 9),
     (16, 256, 8, 4, 0, 2, 8, 9), (16, 512, 16, 4, 0, 1, 4, 9), (16, 512, 16, 4, 1, 1, 4, 9),
 ] + [
-    (tile, h, d, c, t, wps, 8, act)
-    for act in range(1, 9)
-    for (tile, h, d, c, t, wps) in ((32, 128, 16, 8, 0, 1), (32, 128, 16, 8, 1, 1), (16, 256, 8, 4, 1, 2))
+    (16, 256, 8, 4, 1, 2, 8, act) for act in range(1, 9)
 ] + ([
     # round-2 extras (FF_BUILD_FULL): width 256 on the 32-wide tile (A/B runs, FF_TILE=32); up to 32 conditional inputs
     # at width 512 (the wide catch-alls serve them otherwise); the narrow 32-column shapes the 16-column tile replaced;
     # every non-SiLU activation compiled in per width <= 256 and mode, and run-time choice everywhere
     (32, 256, 8, 0, 0, 1, 8, 0), (32, 256, 8, 0, 1, 1, 8, 0),
     (16, 512, 16, 8, 0, 1, 4, 0), (16, 512, 16, 8, 1, 1, 4, 0),
-    (32, 128, 16, 8, 0, 1, 8, 9), (32, 128, 16, 8, 1, 1, 8, 9), (16, 256, 8, 4, 1, 1, 8, 9),
+    (16, 256, 8, 4, 1, 1, 8, 9),
 ] + [
     (32, 128, d, c, t, 1, 8, 0) for d in (4, 8) for c in (0, 8) for t in (0, 1)
 ] + [
     (tile, h, d, c, t, wps, 8, act)
     for act in range(1, 9)
-    for (tile, h, d, c, t, wps) in ((32, 64, 16, 8, 0, 1), (32, 64, 16, 8, 1, 1), (16, 256, 8, 4, 0, 2))
+    for (tile, h, d, c, t, wps) in ((32, 64, 16, 8, 0, 1), (32, 64, 16, 8, 1, 1), (32, 128, 16, 8, 0, 1), (32, 128, 16, 8, 1, 1),
+                                    (16, 256, 8, 4, 0, 2))
 ] if FULL else [])
 
 # Wide catch-alls (kernel template WIDE: cooperative at every batch size, hidden operands read from LDS): networks up
@@ -126,8 +127,10 @@ else:
 
 
 def _has_four_slot_twin(inst) -> bool:
-    """128-wide kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU)."""
-    return inst[2] in (2, 3) and inst[3] == 1 and inst[4] == 128
+    """128-wide kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU, +26 % on the
+    opt-in arithmetic at notebook widths).  Built with FF_BUILD_FULL only since round 3 (12 translation units of a frozen,
+    opt-in family); the launcher's `launch4` pointer is then null and every launch takes the seven-slot kernel."""
+    return FULL and inst[2] in (2, 3) and inst[3] == 1 and inst[4] == 128
 
 
 def _split_name(nh, t, parts=3, dt=1, width=256) -> str:

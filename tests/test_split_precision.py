@@ -646,12 +646,14 @@ def test_split_random_shapes_against_oracle(built_library):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prec", ["bf16x2"])          # (the 128-wide three-part instances and their twins went with round 3's freeze)
+@pytest.mark.parametrize("prec", ["bf16x2"])          # (the 128-wide three-part instances went with round 3's freeze)
 def test_four_slot_twin_is_bitwise_the_seven_slot_kernel(prec, built_library, monkeypatch):
-    """128-wide kernels for states of up to 16 dimensions have a twin with four stage slots on chip (two workgroups per CU; the
-    three-part one also runs its weight DMA one granule ahead instead of two): the launcher picks it when the caller says the table uses at most four slots (ff_ode_args.stage_slots; the front
-    ends pass the method's stage count).  Same arithmetic in the same order: bitwise equal results, for sampling, the
-    Hutchinson and exact-trace log-density and Euler-Maruyama; FF_SPLIT_NO_TWIN=1 pins the seven-slot kernel."""
+    """128-wide kernels for states of up to 16 dimensions have a twin with four stage slots on chip (two workgroups per CU): the
+    launcher picks it when the caller promises a table of at most four slots (ff_ode_args.stage_slots; the front ends pass the
+    method's stage count).  Same arithmetic in the same order: bitwise equal results, for sampling, the Hutchinson and
+    exact-trace log-density and Euler-Maruyama; FF_SPLIT_NO_TWIN=1 pins the seven-slot kernel.  (Since round 3 the twins are
+    compiled with FF_BUILD_FULL only; on the default library both runs take the seven-slot kernel and the test says that the
+    promise changes nothing.)"""
     sm, _, _ = _seeded(9, 3, [128, 100, 128], "VPSDE", True, 71, prec)
     assert _native.kernel_name(sm._net().plan(0)) == ("mlp_ode_split2_h128_n3_t0" if prec == "bf16x2" else "mlp_ode_split_h128_n3_t0")
     torch.manual_seed(6)
