@@ -186,6 +186,11 @@ def extra_configs(device):
     out.append(_record("BASELINE configs[2]: 16-dim VP-SDE 4x256, log_prob, Hutchinson divergence, 100-step RK4, batch 2^20",
                        B, "log-probs/s", wall, name_of(net, 1), kms, 2 * 2.0 * mac_per_eval(DIM, UNITS) * tab.shape[0] * B,
                        {"note": "wall includes the reference's CPU draw of the probe (diffusion.py:701) and its upload"}))
+    # the same call with the probe taken from the counter-based stream on the device (probe="philox": no host draw)
+    sm.log_prob(x0[:256], method="rk4", options=opts, probe="philox", seed=5)
+    _, wall_p, _ = _timed(lambda: sm.log_prob(x0, method="rk4", options=opts, probe="philox", seed=5), device)
+    out[-1]["wall_ms_probe_philox"] = 1e3 * wall_p
+    out[-1]["value_probe_philox"] = B / wall_p
     # the same Hutchinson call on the opt-in 16-bit-operand kernels
     sm.precision = "bf16x2"
     sm.log_prob(x0[:256], method="rk4", options=opts)
@@ -374,8 +379,11 @@ def extra_configs(device):
     return out
 
 
-def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_steps=200, em_steps=1000):
-    """N > 1: the two BASELINE configurations worded for a node, sharded `world` ways, one all-gather each.
+def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_steps=200, em_steps=1000, rows_c3=1 << 20,
+                   logp_steps=N_STEPS):
+    """N > 1: the BASELINE configurations beside the headline, sharded `world` ways, one all-gather each.
+    configs[2]: the headline model's log_prob with the Hutchinson divergence, `logp_steps`-step RK4, `rows_c3` rows over the
+    node; evaluation points and the +-1 probe keyed by the GLOBAL row (distributed.log_prob_sharded, probe="philox").
     configs[3]: 64-dim flow 5x512, `flow_steps`-step fixed Dormand-Prince, `rows_c4` rows over the node; base samples from
     the library's counter-based stream keyed by the GLOBAL row, so every world size transports the same points.
     configs[4]: conditional 32-dim VE 4x256 (8 conditionals), `em_steps`-step Euler-Maruyama, `rows_c5` rows; prior,
@@ -385,7 +393,7 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
     from flowfusion_amd import _native
     from flowfusion_amd import flow as Fm
     from flowfusion_amd.diffusion import MLP, VESDE, ScoreModel
-    from flowfusion_amd.distributed import gather_rows, sample_sde_sharded, shard_bounds
+    from flowfusion_amd.distributed import gather_rows, log_prob_sharded, sample_sde_sharded, shard_bounds
     gather_dev = device if backend == "nccl" else torch.device("cpu")
     recs, invariant = [], True
 
@@ -403,6 +411,34 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
         dist.all_gather(allr, mine)
         return [[float(t[i]) for t in allr] for i in range(len(values))]
 
+    # --- configs[2] ---------------------------------------------------------------------------------------------------
+    sm3 = build_model(device)
+    sm3.hutch = True
+    lo, hi = shard_bounds(rows_c3, world, rank)
+    x3 = _native.normal_fill(hi - lo, DIM, 4321, lo, device, scale=0.8)
+    o3 = {"step_size": (1.0 - float(sm3.sde.epsilon)) / logp_steps}
+    kw3 = {"local_x": x3, "n_total": rows_c3, "seed": 5, "gather": False, "method": "rk4", "options": o3}
+    sm3.log_prob(x3[:64].contiguous(), method="rk4", options=o3, probe="philox", seed=5, sample_offset=lo)
+    dist.barrier()
+    (lp, _), wall, kms = _timed(lambda: log_prob_sharded(sm3, **kw3), device)
+    full, gms = timed_gather(lp, rows_c3)
+    head = sm3.log_prob(x3[:256].contiguous(), method="rk4", options=o3, probe="philox", seed=5, sample_offset=lo)
+    ok3 = bool(torch.equal(head, lp[:256])) and bool(torch.equal(full[lo:lo + 256].to(device), lp[:256]))
+    invariant &= ok3
+    walls, kmss, gmss = per_rank([1e3 * wall, kms, gms])
+    n_evals3 = 4 * logp_steps
+    slow = max(w + g for w, g in zip(walls, gmss)) * 1e-3
+    recs.append({"workload": f"BASELINE configs[2]: 16-dim VP-SDE 4x256 log_prob, Hutchinson divergence, {logp_steps}-step RK4, "
+                             f"{rows_c3} rows sharded over {world} GPUs, probe keyed by the global row, one all-gather",
+                 "value": rows_c3 / slow, "unit": "log-probs/s", "rows_per_rank": hi - lo,
+                 "kernel": _native.kernel_name(sm3._net().plan(1)),
+                 "per_rank": {"wall_ms": walls, "kernel_ms": kmss, "allgather_ms": gmss}, "dtype": "f32",
+                 "roofline": {"bound": "mfma", "achieved": 4.0 * mac_per_eval(DIM, UNITS) * n_evals3 * (hi - lo) / (kms * 1e-3) / 1e12,
+                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": 4.0 * mac_per_eval(DIM, UNITS) * n_evals3 * (hi - lo) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                              "note": "rank 0's launch (probe draw on the device included in kernel_ms); value + tangent column "
+                                      "= 2x the state-only work"}, "rank_invariant": ok3})
+    del sm3, x3, lp, full, head
     # --- configs[3] ---------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
     f = Fm.ODEFlow(64, [512] * 5).to(device).eval()
@@ -520,6 +556,8 @@ def main():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--c4-rows", type=int, default=1 << 22, help="N > 1: rows of BASELINE configs[3] over the node")
     ap.add_argument("--c5-rows", type=int, default=1 << 20, help="N > 1: rows of BASELINE configs[4] over the node")
+    ap.add_argument("--c3-rows", type=int, default=1 << 20, help="N > 1: rows of BASELINE configs[2] (log_prob) over the node")
+    ap.add_argument("--c3-steps", type=int, default=N_STEPS, help="N > 1: RK4 steps of configs[2]")
     ap.add_argument("--c4-steps", type=int, default=200, help="N > 1: fixed steps of configs[3] (rehearsals shorten it)")
     ap.add_argument("--c5-steps", type=int, default=1000, help="N > 1: Euler-Maruyama steps of configs[4]")
     args = ap.parse_args()
@@ -545,6 +583,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # communicator set-up (RCCL builds its rings on the first collective) happens here, whatever --warmup says
+        dist.all_reduce(torch.zeros(1, device=device if args.backend == "nccl" else "cpu"))
 
     # host threads: the ranks of a node share its cores (table building, packing, the gloo rehearsal's copies)
     host_threads = max(1, usable_cores() // world)
@@ -619,7 +659,7 @@ def main():
         if args.extras:
             try:
                 sharded, ok = sharded_extras(device, world, rank, dist, args.backend, args.c4_rows, args.c5_rows,
-                                             args.c4_steps, args.c5_steps)
+                                             args.c4_steps, args.c5_steps, args.c3_rows, args.c3_steps)
                 rank_invariant &= ok
             except Exception as exc:      # the headline measurement above must still be reported (ONE line, rank 0)
                 sharded = [{"workload": "sharded BASELINE configs[3] / configs[4] (extras of the N > 1 run)", "error": repr(exc)}]

@@ -153,6 +153,7 @@ class NormTerm(ctypes.Structure):         # ff_norm_term
 
 NORM_TERMS = 3                      # FF_NORM_TERMS
 PRIOR_NOISE_INDEX = 0xFFFFFFFF     # FF_PRIOR_NOISE_INDEX
+PROBE_NOISE_INDEX = 0xFFFFFFFE     # FF_PROBE_NOISE_INDEX
 
 _lib = None
 

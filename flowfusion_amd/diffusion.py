@@ -602,13 +602,34 @@ class ScoreModel(nn.Module):
 
     @torch.no_grad()
     def solve_odes_forward(self, x0_samples, conditional=None, atol=1e-5, rtol=1e-5,
-                           method="dopri5", options=None):
+                           method="dopri5", options=None, *, probe="torch", seed=None, sample_offset=0):
         """Probability-flow ODE from epsilon up to t=1 with the divergence integrated alongside;
-        returns ``(xT, delta_logp[B,1])`` (reference: diffusion.py:642-754)."""
-        return self._solve_forward(x0_samples, conditional, atol, rtol, method, options)
+        returns ``(xT, delta_logp[B,1])`` (reference: diffusion.py:642-754).
+
+        Extension, keyword only (Hutchinson models): ``probe="torch"`` (default) draws the +-1 probe on the CPU and
+        moves it, exactly as the reference does (:701), so ``torch.manual_seed`` reproduces its stream;
+        ``probe="philox"`` takes the signs of the library's counter-based normals keyed by ``seed`` and the GLOBAL row
+        ``sample_offset + r`` (``ff_normal_fill`` with the reserved probe index): drawn on the device (no host draw, no
+        upload) and independent of how a batch is cut into shards (``distributed.log_prob_sharded``)."""
+        return self._solve_forward(x0_samples, conditional, atol, rtol, method, options,
+                                   probe_rng=self._probe_rng(probe, seed, sample_offset))
+
+    def _probe_rng(self, probe, seed, sample_offset):
+        if probe == "torch":
+            if seed is not None:
+                raise ValueError("seed= belongs to probe='philox' (the torch probe follows torch.manual_seed)")
+            return None
+        if probe != "philox":
+            raise ValueError(f"probe must be 'torch' or 'philox', not {probe!r}")
+        if not self.hutch:
+            raise ValueError("probe='philox' is the Hutchinson probe: construct the model with hutchinson=True")
+        if seed is None:      # one draw of torch's generator, so torch.manual_seed still fixes the run
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return int(seed), int(sample_offset)
 
     @torch.no_grad()
-    def _solve_forward(self, x0_samples, conditional, atol, rtol, method, options, in_shift=None, in_scale=None):
+    def _solve_forward(self, x0_samples, conditional, atol, rtol, method, options, in_shift=None, in_scale=None,
+                       probe_rng=None):
         """solve_odes_forward proper; ``(x - in_shift) / in_scale`` (PopulationModel*.log_prob,
         diffusion.py:1633, 1837) is applied by the kernel's prologue."""
         fused = self._fusable()
@@ -634,7 +655,13 @@ class ScoreModel(nn.Module):
             return xT, dlogp.view(-1, 1)
         probe = None
         mode = MODE_EXACT
-        if self.hutch:
+        if self.hutch and probe_rng is not None:
+            if x0_samples.dim() != 2:
+                raise NotImplementedError("probe='philox': only [batch, dim] states")
+            z = _native.normal_fill(x0_samples.shape[0], x0_samples.shape[1], probe_rng[0], probe_rng[1],
+                                    x0_samples.device, noise_index=_native.PROBE_NOISE_INDEX)
+            self.e = torch.where(z >= 0, 1.0, -1.0).to(torch.float32)
+        elif self.hutch:
             # drawn on the CPU and moved, as the reference does (diffusion.py:701)
             self.e = torch.sign(torch.randn(x0_samples.shape)).to(x0_samples.device)
             probe = self.e
@@ -691,10 +718,12 @@ class ScoreModel(nn.Module):
 
     @torch.no_grad()
     def log_prob(self, x0_samples, conditional=None, atol=1e-4, rtol=1e-4, method="dopri5",
-                 options={"min_step": 1e-6}):
-        """log p(x0) = delta_logp + log prior(xT), shape [B,1] (reference: diffusion.py:756-815)."""
+                 options={"min_step": 1e-6}, *, probe="torch", seed=None, sample_offset=0):
+        """log p(x0) = delta_logp + log prior(xT), shape [B,1] (reference: diffusion.py:756-815).  ``probe`` / ``seed`` /
+        ``sample_offset``: see ``solve_odes_forward``."""
         xT, lp = self.solve_odes_forward(x0_samples, conditional=conditional, atol=atol, rtol=rtol,
-                                         method=method, options=options)
+                                         method=method, options=options, probe=probe, seed=seed,
+                                         sample_offset=sample_offset)
         return lp + torch.sum(self.sde.prior(xT.shape).log_prob(xT), dim=1, keepdim=True)
 
 

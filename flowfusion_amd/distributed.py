@@ -94,3 +94,42 @@ def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] =
     if not gather:
         return local, (lo, hi)
     return gather_rows(local, batch, group) if world > 1 else local
+
+
+def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional: Optional[torch.Tensor] = None,
+                     seed: int = 0, group=None, gather: bool = True, local_x: Optional[torch.Tensor] = None,
+                     n_total: Optional[int] = None, local_conditional: Optional[torch.Tensor] = None, **solver):
+    """``ScoreModel.log_prob`` of a [B, dim] batch over all ranks; one all-gather of the [B, 1] result at the end.
+
+    ``x`` (and ``conditional``) are the full tensors, every rank slicing its rows -- or ``local_x`` (and
+    ``local_conditional``) are this rank's rows already, with ``n_total`` the size of the whole batch.  A Hutchinson
+    model takes its probe from the library's counter-based stream keyed by ``seed`` and the GLOBAL row
+    (``probe="philox"``), so with a fixed-grid ``method`` a row's result does not depend on the number of ranks; the
+    exact trace needs no random numbers.  ``**solver`` (atol, rtol, method, options) goes to ``log_prob`` unchanged.
+    Under an adaptive ``method`` every rank controls its steps from the error norm of its own rows (torchdiffeq's norm
+    is over the batch it is handed), so results then agree across world sizes to the tolerances, not bit for bit."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if (x is None) == (local_x is None):
+        raise ValueError("pass either the full batch `x` or this rank's rows `local_x` (with n_total)")
+    if x is not None:
+        n = x.shape[0]
+        lo, hi = shard_bounds(n, world, rank)
+        rows = x[lo:hi].contiguous()
+        if local_conditional is not None:
+            raise ValueError("local_conditional goes with local_x")
+        cond = None if conditional is None else conditional[lo:hi].contiguous()
+    else:
+        if n_total is None or conditional is not None:
+            raise ValueError("local_x needs n_total (and local_conditional instead of conditional)")
+        n = int(n_total)
+        lo, hi = shard_bounds(n, world, rank)
+        if local_x.shape[0] != hi - lo or (local_conditional is not None and local_conditional.shape[0] != hi - lo):
+            raise ValueError(f"rank {rank} of {world} owns rows [{lo}, {hi}) of {n}: local tensors must hold exactly those")
+        rows = local_x.contiguous()
+        cond = None if local_conditional is None else local_conditional.contiguous()
+    extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if getattr(score_model, "hutch", False) else {}
+    local = score_model.log_prob(rows, conditional=cond, **solver, **extra)
+    if not gather:
+        return local, (lo, hi)
+    return gather_rows(local, n, group) if world > 1 else local

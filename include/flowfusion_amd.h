@@ -265,6 +265,10 @@ int ff_last_hip_error(void);
 /* Noise index reserved for the prior draw of a sample in the counter-based stream (never used by the
  * Euler-Maruyama rows, which count from rng_noise_base upwards). */
 #define FF_PRIOR_NOISE_INDEX 0xFFFFFFFFu
+/* Noise index reserved for the Hutchinson probe of a sample: e = sign(z(seed, global row, this index, d)) replaces the
+ * host draw `torch.sign(torch.randn(shape)).to(device)` (diffusion.py:701) when a log-density batch is sharded over GPUs
+ * or the host draw should leave the critical path (host side: probe="philox"). */
+#define FF_PROBE_NOISE_INDEX 0xFFFFFFFEu
 
 /*
  * out[r][d] = scale * z(seed, global row sample_offset + r, noise_index, d)  for r < batch, d < dim, with z the

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flowfusion_amd.distributed import gather_rows, run_sharded, shard_bounds, shard_sizes
+from flowfusion_amd.distributed import gather_rows, log_prob_sharded, run_sharded, shard_bounds, shard_sizes
 
 
 def test_shard_bounds_cover_and_balance():
@@ -54,6 +54,61 @@ def test_sharding_and_gather_over_gloo(world, n):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+class _RowKeyedModel:
+    """Stand-in for a Hutchinson ScoreModel: log_prob(rows) depends on each row's values, its conditional and the GLOBAL
+    row index it is told (sample_offset + r) -- what the counter-based probe makes true of the real one."""
+    hutch = True
+
+    def log_prob(self, rows, conditional=None, probe="torch", seed=None, sample_offset=0, **solver):
+        assert probe == "philox" and solver == {"method": "rk4", "options": {"step_size": 0.1}}
+        g = torch.arange(rows.shape[0], dtype=torch.float32) + float(sample_offset)
+        c = 0.0 if conditional is None else conditional.sum(1)
+        return (rows.sum(1) + 1000.0 * g + float(seed) + c).view(-1, 1)
+
+
+def _logp_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        x, c = torch.randn(n, 5), torch.randn(n, 2)
+        m = _RowKeyedModel()
+        kw = {"method": "rk4", "options": {"step_size": 0.1}}
+        expect = m.log_prob(x, conditional=c, probe="philox", seed=9, sample_offset=0, **kw)
+        full = log_prob_sharded(m, x, c, seed=9, **kw)
+        ok = torch.equal(full, expect)
+        lo, hi = shard_bounds(n, world, rank)
+        mine = log_prob_sharded(m, local_x=x[lo:hi], local_conditional=c[lo:hi], n_total=n, seed=9, **kw)
+        ok &= torch.equal(mine, expect)
+        local, span = log_prob_sharded(m, x, c, seed=9, gather=False, **kw)
+        ok &= span == (lo, hi) and torch.equal(local, expect[lo:hi])
+        try:
+            log_prob_sharded(m, local_x=x[: hi - lo + 1], n_total=n, seed=9, **kw)
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 37), (8, 64), (8, 5)])
+def test_log_prob_sharded_over_gloo(world, n):
+    """The sharded log-density helper: every rank is told the global index of its first row (the key of the probe
+    stream), full-batch and local-rows calling conventions agree, one all-gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_logp_worker, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -14,6 +14,7 @@ the oracle (1e-6..1e-5 after hundreds of sequential network evaluations); the te
 trajectories grow to O(10^2..10^3)), log-densities relative with an absolute floor of 1 -- which is
 tight enough to expose a single wrong operand register in one layer.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -152,6 +153,50 @@ def test_hutchinson_log_prob_against_oracle(name):
     assert lp.shape == (B, 1)
     assert _logp_err(lp, ref32) < LOGP_TOL, name
     assert _logp_err(lp, ref64.float()) < LOGP_TOL, name
+
+
+def test_hutchinson_probe_from_the_counter_based_stream():
+    """probe="philox": the +-1 probe is the sign of the library's counter-based normals keyed by (seed, global row) --
+    drawn on the device, reproducible, independent of how the batch is cut; the log-density equals the oracle's for
+    that probe, and a slice of the batch solved on its own (distributed.log_prob_sharded on one rank of many) returns
+    the rows of the whole-batch solve bit for bit."""
+    from flowfusion_amd import _native
+    from flowfusion_amd.distributed import log_prob_sharded
+    from tests._philox import normals
+    sm, so32, so64 = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 12)
+    sm.hutch = True
+    torch.manual_seed(4321)
+    B = 300
+    x0 = torch.randn(B, 16) * 0.8 + 0.3
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 25}
+    lp = sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox", seed=77)
+    e = sm.e.cpu()
+    assert set(e.unique().tolist()) == {-1.0, 1.0}
+    z = normals(77, 0, B, 16, [_native.PROBE_NOISE_INDEX])[0]
+    far = np.abs(z) > 1e-5                                 # hardware log / sin / cos vs numpy near zero
+    assert np.array_equal(e.numpy()[far], np.where(z >= 0, 1.0, -1.0)[far]) and far.mean() > 0.999
+    assert abs(float(e.mean())) < 0.05
+    ref64 = so64.log_prob(x0.double(), None, "rk4", opts, "hutch", e.double())
+    assert _logp_err(lp, ref64.float()) < LOGP_TOL
+    again = sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox", seed=77)
+    other = sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox", seed=78)
+    assert torch.equal(lp, again) and not torch.equal(lp, other)
+    lo, hi = 100, 237
+    part = sm.log_prob(x0[lo:hi].to(DEV), method="rk4", options=opts, probe="philox", seed=77, sample_offset=lo)
+    assert torch.equal(part, lp[lo:hi])
+    whole = log_prob_sharded(sm, x0.to(DEV), seed=77, method="rk4", options=opts)       # one process: the whole batch
+    assert torch.equal(whole, lp)
+    torch.manual_seed(3)                                   # seed=None: one draw of torch's generator fixes the run
+    a = sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox")
+    torch.manual_seed(3)
+    assert torch.equal(a, sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox"))
+    with pytest.raises(ValueError):
+        sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="curand")
+    with pytest.raises(ValueError):
+        sm.log_prob(x0.to(DEV), method="rk4", options=opts, seed=5)                      # seed= without probe="philox"
+    sm.hutch = False
+    with pytest.raises(ValueError):
+        sm.log_prob(x0.to(DEV), method="rk4", options=opts, probe="philox")
 
 
 def test_exact_trace_log_prob_against_oracle():
