@@ -664,6 +664,7 @@ class ScoreModel(nn.Module):
         elif self.hutch:
             # drawn on the CPU and moved, as the reference does (diffusion.py:701)
             self.e = torch.sign(torch.randn(x0_samples.shape)).to(x0_samples.device)
+        if self.hutch:
             probe = self.e
             mode = MODE_HUTCH
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
