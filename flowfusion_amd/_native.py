@@ -18,6 +18,7 @@ FF_OK = 0
 FF_ERR_BADARG = -1
 FF_ERR_UNSUPPORTED = -2
 FF_ERR_HIP = -3
+FF_ERR_EXCHANGE = -4
 
 MODE_STATE = 0
 MODE_HUTCH = 1
@@ -127,7 +128,12 @@ class AdaptBuffers(ctypes.Structure):     # ff_adapt_buffers
         ("norm_workspace", ctypes.c_void_p), ("norm_only", ctypes.c_void_p * 2), ("norm_only_n", ctypes.c_int64 * 2),
         ("n_passes", ctypes.c_int32), ("pass_first", ctypes.c_int32 * ADAPT_MAX_PASSES),
         ("pass_count", ctypes.c_int32 * ADAPT_MAX_PASSES),
+        ("exchange_sums", ctypes.c_void_p), ("exchange", ctypes.c_void_p), ("exchange_user", ctypes.c_void_p),
     ]
+
+
+EXCHANGE_DOUBLES = 8                      # FF_EXCHANGE_DOUBLES
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)      # int (*exchange)(void* user, void* stream)
 
 
 class CombineArgs(ctypes.Structure):      # ff_combine_args
@@ -225,7 +231,8 @@ def lib() -> ctypes.CDLL:
 
 
 def _err(rc: int, what: str) -> RuntimeError:
-    names = {FF_ERR_BADARG: "FF_ERR_BADARG", FF_ERR_UNSUPPORTED: "FF_ERR_UNSUPPORTED", FF_ERR_HIP: "FF_ERR_HIP"}
+    names = {FF_ERR_BADARG: "FF_ERR_BADARG", FF_ERR_UNSUPPORTED: "FF_ERR_UNSUPPORTED", FF_ERR_HIP: "FF_ERR_HIP",
+             FF_ERR_EXCHANGE: "FF_ERR_EXCHANGE"}
     extra = f" (hipError {lib().ff_last_hip_error()})" if rc == FF_ERR_HIP else ""
     return RuntimeError(f"{what} failed: {names.get(rc, rc)}{extra}")
 

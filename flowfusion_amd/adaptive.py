@@ -19,6 +19,7 @@ the GPU tests compare against.
 """
 from __future__ import annotations
 
+import math
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -129,7 +130,17 @@ def _rms(t: torch.Tensor) -> torch.Tensor:
 
 
 def _mixed_norm(parts) -> float:
-    """max over the components of the tuple state of their RMS norms (torchdiffeq `_mixed_norm`)."""
+    """max over the components of the tuple state of their RMS norms (torchdiffeq `_mixed_norm`).  Inside
+    ``distributed.global_step_control`` the components are shards of a batch cut over ranks: their sums of squares and
+    element counts meet before the root is taken."""
+    from . import distributed
+    exchange, group = distributed.step_control_group()
+    if exchange:
+        parts = [p for p in parts if p is not None]
+        tot = distributed.sum_over_ranks([float(p.double().pow(2).sum()) for p in parts] + [float(p.numel()) for p in parts],
+                                         parts[0].device, group)
+        k = len(parts)
+        return max(math.sqrt(tot[j] / tot[k + j]) for j in range(k) if tot[k + j] > 0)
     return max(float(_rms(p)) for p in parts if p is not None and p.numel() > 0)
 
 
@@ -225,12 +236,21 @@ class Dopri5:
         only host synchronisation of an attempted step.  (CPU tensors -- the kernel-semantics emulator of the tests --
         take the same arithmetic in torch ops.)"""
         if terms[0][0].is_cuda:
-            from . import _native
+            from . import _native, distributed
+            exchange, group = distributed.step_control_group()
             out = []
             for i in range(0, len(terms), _native.NORM_TERMS):
                 part = terms[i:i + _native.NORM_TERMS]
                 vals = _native.scaled_rms([tuple(None if t is None else t.reshape(-1) for t in term) for term in part],
                                           self.atol, self.rtol, check.reshape(-1) if (check is not None and i == 0) else None)
+                if exchange:
+                    # several shards of one batch (distributed.global_step_control): mean squares -> sums of squares,
+                    # summed over the ranks with the element counts -> the norms of the whole batch
+                    cnt = [float(term[0].numel()) for term in part]
+                    tot = distributed.sum_over_ranks([float(v) ** 2 * n for v, n in zip(vals, cnt)] + cnt
+                                                     + [float(vals[len(part)])], terms[0][0].device, group)
+                    k = len(part)
+                    vals = [math.sqrt(tot[j] / tot[k + j]) if tot[k + j] > 0 else 0.0 for j in range(k)] + [tot[2 * k]]
                 out.extend(vals[:len(part)])
                 if i == 0:
                     bad = vals[len(part)] != 0.0
@@ -239,7 +259,12 @@ class Dopri5:
         for num, sub, s0, s1 in terms:
             sc = s0.abs() if s1 is None else torch.max(s0.abs(), s1.abs())
             parts.append((num if sub is None else num - sub) / (self.atol + self.rtol * sc))
-        return _mixed_norm(parts), (not bool(torch.isfinite(check).all()) if check is not None else False)
+        bad = not bool(torch.isfinite(check).all()) if check is not None else False
+        from . import distributed
+        exchange, group = distributed.step_control_group()
+        if exchange and check is not None:
+            bad = distributed.sum_over_ranks([1.0 if bad else 0.0], check.device, group)[0] > 0
+        return _mixed_norm(parts), bad
 
     def _select_initial_step(self, t0, y, lp, f0, fl0):
         if y.is_cuda:

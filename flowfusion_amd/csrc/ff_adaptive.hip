@@ -41,6 +41,8 @@ struct ControlArgs {
     int etab_stride;       // FF_ROW_HDR + plan width
     int phase;
     double t0, t_end;      // kPhaseInit0 only
+    int stage;             // 0: norms and controller in one launch; several shards of one batch (ff_adapt_buffers.exchange):
+    double* gsums;         // 1 = reduce into gsums, 2 = controller from gsums after they were summed over the ranks
 };
 
 // words of one evaluation row of the table for real time `t_real`; `feat` = the row's time features (LDS)
@@ -91,9 +93,21 @@ __global__ __launch_bounds__(256) void adapt_control_kernel(const ControlArgs a)
     // launches enqueued behind the end of the solve do nothing (uniform: nobody writes `active` before the last block)
     if (a.phase == adapt::kPhaseStep && *(const volatile int*)&a.state->active == 0) return;
 
-    bool is_last = true;
-    if (a.norm.n_terms > 0 || a.norm.n_check > 0) is_last = scaled_rms_reduce(a.norm, sh, &last, res);
-    if (!is_last) return;
+    if (a.stage == 2) {
+        // the sums of squares of every rank's rows have met: the norms are over the whole batch
+        if (threadIdx.x == 0) {
+            for (int t = 0; t < FF_NORM_TERMS; ++t) {
+                const double cnt = a.gsums[FF_NORM_TERMS + 1 + t];
+                res[t] = cnt > 0.0 ? (float)sqrt(a.gsums[t] / cnt) : 0.f;
+            }
+            res[FF_NORM_TERMS] = a.gsums[FF_NORM_TERMS] > 0.0 ? 1.f : 0.f;
+        }
+        __syncthreads();
+    } else {
+        bool is_last = true;
+        if (a.norm.n_terms > 0 || a.norm.n_check > 0) is_last = scaled_rms_reduce(a.norm, sh, &last, res);
+        if (!is_last || a.stage == 1) return;
+    }
 
     const ff_adapt_config& c = a.cfg;
     if (threadIdx.x == 0) {
@@ -294,6 +308,14 @@ struct Driver {
         }
         k.cfg = *cfg; k.state = b->state; k.etab = b->etab; k.etab_stride = FF_ROW_HDR + plan->width;
         k.phase = phase; k.t0 = t0; k.t_end = t_end;
+        if (b->exchange && (n_terms > 0 || n_check > 0)) {
+            // this rank's sums of squares -> summed over the ranks (enqueued by the caller's hook) -> the controller
+            k.stage = 1; k.gsums = b->exchange_sums; k.norm.sums = b->exchange_sums;
+            hipLaunchKernelGGL(ff::adapt_control_kernel, dim3(grid), dim3(256), 0, stream, k);
+            if (hipGetLastError() != hipSuccess) return FF_ERR_HIP;
+            if (b->exchange(b->exchange_user, (void*)stream) != 0) return FF_ERR_EXCHANGE;
+            k.stage = 2; k.norm.sums = nullptr; grid = 1;
+        }
         hipLaunchKernelGGL(ff::adapt_control_kernel, dim3(grid), dim3(256), 0, stream, k);
         return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;
     }
@@ -358,7 +380,8 @@ extern "C" int ff_mlp_ode_adaptive(const ff_mlp_plan_t* plan, const ff_ode_args*
     if (has_lp && (!b->lp || !b->fl0 || !b->scratch_lp || !b->out_lp)) return FF_ERR_BADARG;
     if (b->n_passes < 1 || b->n_passes > FF_ADAPT_MAX_PASSES || (b->n_passes > 1 && (!has_lp || !b->aux_lp_pass))) return FF_ERR_BADARG;
     if (base->batch < 0) return FF_ERR_BADARG;
-    if (base->batch == 0) return FF_OK;
+    if (b->exchange && !b->exchange_sums) return FF_ERR_BADARG;
+    if (base->batch == 0) return b->exchange ? FF_ERR_UNSUPPORTED : FF_OK;     // an empty shard cannot take part in the exchange
 
     Driver d{plan, base, cfg, b, (hipStream_t)hip_stream, (long long)base->batch, (long long)plan->dim, has_lp};
     const long long nBD = d.B * d.D, nB = d.B;

@@ -551,6 +551,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) kl[s] = 0.f;
     float lp = 0.f;
+    // Cooperative twin: the four wavefronts share the slots.  Everything they store there later is the same value from
+    // each of them, so late or repeated stores are harmless -- except this zero fill: a wavefront that starts late would
+    // wipe the caller's first stage (below) between another wavefront's store and its first read.  All fills first.
+    if constexpr (COOP) __syncthreads();
     if (args.k1_in) {            // first stage supplied by the caller (FSAL of the previous step)
 #pragma unroll
         for (int j = 0; j < R4; ++j) {

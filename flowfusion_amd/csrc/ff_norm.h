@@ -33,6 +33,8 @@ struct NormArgs {
     float* out;
     unsigned* counter;
     double* partial;       // [kNormBlocks][FF_NORM_TERMS + 1]
+    double* sums;          // optional [2 * FF_NORM_TERMS + 2]: the raw sums of squares, the non-finite count and the element
+                           // counts instead of the norms (they meet the other ranks' before the norms are taken)
 };
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -135,7 +137,10 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
             for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
                 acc += __builtin_nontemporal_load(&a.partial[(size_t)b * (FF_NORM_TERMS + 1) + col]);
             const double tot = block_sum(acc, sh);
-            if (threadIdx.x == 0) {
+            if (threadIdx.x == 0 && a.sums) {
+                a.sums[col] = tot;
+                if (t < a.n_terms) a.sums[FF_NORM_TERMS + 1 + t] = (double)a.n[t];
+            } else if (threadIdx.x == 0) {
                 if (t < a.n_terms) {
                     res[t] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
                     if (a.out) a.out[t] = res[t];
@@ -145,6 +150,8 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
                 }
             }
         }
+        if (threadIdx.x == 0 && a.sums)
+            for (int t = a.n_terms; t < FF_NORM_TERMS; ++t) { a.sums[t] = 0.0; a.sums[FF_NORM_TERMS + 1 + t] = 0.0; }
         if (threadIdx.x == 0) *a.counter = 0u;          // ready for the next launch on this stream
         __syncthreads();
     }
@@ -169,6 +176,7 @@ inline unsigned norm_args_from_terms(NormArgs& k, const ff_norm_term* terms, int
     k.check = check; k.n_check = n_check; k.n_terms = n_terms; k.atol = atol; k.rtol = rtol; k.out = out;
     k.counter = (unsigned*)workspace;
     k.partial = (double*)((char*)workspace + 16);
+    k.sums = nullptr;
     long long want = (most / 4 + 255) / 256;              // one 16-byte access per thread and trip
     return (unsigned)(want < 1 ? 1 : (want > kNormBlocks ? kNormBlocks : want));
 }

@@ -31,6 +31,7 @@ TRACE = None              # diagnostics: a list collects (attempts, accepted, t,
                           # (one attempt per chunk while it is set; scratch/diag_adaptive_pair.py)
 TRACE_ROWS = False        # ... and a host copy of the evaluation table the controller wrote for the NEXT attempt (tests)
 MAX_CHUNK = 64
+POISON = None             # tests: a value the work buffers are filled with before the solve (uninitialised reads show)
 MAX_TIME_COLS = 64        # kMaxTimeCols of ff_adaptive.hip
 
 
@@ -126,7 +127,12 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
     keep: list = []
     cfg = build_config(spec, sign, method, rtol, atol, options, keep)
     net.require_slots(cfg.n_stages, mode, "this adaptive method")
+    from . import distributed
+    exchange, group = distributed.step_control_group()
     if B == 0:
+        if exchange:
+            raise ValueError("global_step_control: every rank needs at least one row of the batch (an empty shard cannot "
+                             "take part in the exchange of the error norms)")
         return x.new_empty(0, D), (x.new_empty(0) if has_lp else None), {"attempts": 0, "accepted": 0, "chunks": 0}
     passes = [(0, 0)] if mode != MODE_EXACT else list(_passes(net, plan))
     P = len(passes)
@@ -144,6 +150,8 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
     if has_lp:
         sizes += [nB] * (2 + 4 + 1) + ([P * 4 * nB] if P > 1 else [])
     flat = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
+    if POISON is not None:
+        flat.fill_(POISON)          # tests: nothing may be read from the work buffers before the solve wrote it
     v = _carve(flat, sizes)
     state, y, f0, aux, scratch_x, etab = v[0], v[1], v[2], v[3:7], v[7], v[8]
     out_y = torch.empty(B, D, dtype=torch.float32, device=dev)
@@ -179,6 +187,23 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
         raise RuntimeError(f"cond has shape {tuple(cond_d.shape)}, expected {(B, plan.cond_dim)}")
     if probe_d is not None and tuple(probe_d.shape) != (B, D):
         raise RuntimeError(f"probe has shape {tuple(probe_d.shape)}, expected {(B, D)}")
+    hook_error: list = []
+    if exchange:
+        # the sums of squares behind every norm meet the other ranks' between the reduction and the controller launch:
+        # the C driver calls back here, the all-reduce is enqueued behind the reduction on the same stream
+        sums = torch.zeros(_native.EXCHANGE_DOUBLES, dtype=torch.float64, device=dev)
+
+        def _hook(_user, _stream):
+            try:
+                distributed.sum_over_ranks_(sums, group)
+                return 0
+            except Exception as exc:          # noqa: BLE001 -- reported by the caller below, not through the C frame
+                hook_error.append(exc)
+                return 1
+        hook = _native.EXCHANGE_FN(_hook)
+        keep.extend([sums, hook])
+        b.exchange_sums = sums.data_ptr()
+        b.exchange = ctypes.cast(hook, ctypes.c_void_p).value
     L = _native.lib()
     first_chunk = 1 if TRACE is not None else int(os.environ.get("FF_ADAPT_CHUNK", FIRST_CHUNK))
     what, n, chunks = _native.ADAPT_START | _native.ADAPT_FINISH, first_chunk, 0
@@ -191,6 +216,8 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
                                        float(t0), float(t_end), what, n, ctypes.c_void_p(stream))
             if rc != _native.FF_OK:
                 ws[:4].zero_()
+                if hook_error:
+                    raise RuntimeError("global_step_control: the all-reduce of the error norms failed") from hook_error[0]
                 raise _native._err(rc, "ff_mlp_ode_adaptive")
             chunks += 1
             st = _native.AdaptState.from_buffer_copy(state.view(torch.int32).cpu().numpy().tobytes())

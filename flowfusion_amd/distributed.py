@@ -9,10 +9,59 @@ all-gather over xGMI (backend "nccl" is RCCL on ROCm).  No other collective is u
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Sequence, Tuple
+import contextlib
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+# ---- the one exchange step of the path: step control of an ADAPTIVE solve over several shards of one batch -----------------
+_STEP_CONTROL = {"active": False, "group": None}
+
+
+@contextlib.contextmanager
+def global_step_control(group=None):
+    """Adaptive solves inside this context control their step size from the error norm of the WHOLE batch, as torchdiffeq
+    does for the batch it is handed (one step size for all samples: diffusion.py:631-639, 744-752; flow.py:299-303,
+    371-382), although each rank holds only a shard: the sums of squares behind every norm are summed over ``group``
+    (an RCCL all-reduce of 8 doubles per norm, enqueued between the reduction kernel and the controller kernel -- no host
+    synchronisation on the device-side controller).  Every rank then takes the same accept / reject decisions and the same
+    steps, so a sample's result does not depend on the sharding beyond the rounding of those sums.  Every rank must enter
+    the same solves in the same order, each with at least one row.  Outside the context (the default) a rank controls its
+    steps from its own rows.  Fixed-grid solves need none of this."""
+    if not dist.is_initialized():
+        raise RuntimeError("global_step_control needs an initialised torch.distributed process group")
+    prev = dict(_STEP_CONTROL)
+    _STEP_CONTROL.update(active=True, group=group)
+    try:
+        yield
+    finally:
+        _STEP_CONTROL.update(prev)
+
+
+def step_control_group():
+    """(active, group) of the enclosing ``global_step_control`` context."""
+    return _STEP_CONTROL["active"], _STEP_CONTROL["group"]
+
+
+def sum_over_ranks_(values: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum of a small tensor over the ranks, ordered with the current stream.  RCCL reduces device tensors in
+    place; the gloo rehearsal (several ranks on one card, CPU tests) goes through the host."""
+    if dist.get_backend(group) == "nccl" or not values.is_cuda:
+        dist.all_reduce(values, group=group)
+    else:
+        host = values.cpu()
+        dist.all_reduce(host, group=group)
+        values.copy_(host)
+    return values
+
+
+def sum_over_ranks(values: List[float], device, group=None) -> List[float]:
+    """Host-side form (the host step controller): python floats in, their sums over the ranks out."""
+    on = device if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor(values, dtype=torch.float64, device=on)
+    dist.all_reduce(t, group=group)
+    return [float(v) for v in t.cpu()]
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
@@ -98,7 +147,8 @@ def sample_sde_sharded(score_model, shape, conditional: Optional[torch.Tensor] =
 
 def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional: Optional[torch.Tensor] = None,
                      seed: int = 0, group=None, gather: bool = True, local_x: Optional[torch.Tensor] = None,
-                     n_total: Optional[int] = None, local_conditional: Optional[torch.Tensor] = None, **solver):
+                     n_total: Optional[int] = None, local_conditional: Optional[torch.Tensor] = None,
+                     global_control: bool = True, **solver):
     """``ScoreModel.log_prob`` of a [B, dim] batch over all ranks; one all-gather of the [B, 1] result at the end.
 
     ``x`` (and ``conditional``) are the full tensors, every rank slicing its rows -- or ``local_x`` (and
@@ -106,8 +156,10 @@ def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional:
     model takes its probe from the library's counter-based stream keyed by ``seed`` and the GLOBAL row
     (``probe="philox"``), so with a fixed-grid ``method`` a row's result does not depend on the number of ranks; the
     exact trace needs no random numbers.  ``**solver`` (atol, rtol, method, options) goes to ``log_prob`` unchanged.
-    Under an adaptive ``method`` every rank controls its steps from the error norm of its own rows (torchdiffeq's norm
-    is over the batch it is handed), so results then agree across world sizes to the tolerances, not bit for bit."""
+    Under an adaptive ``method`` (the reference's default) the step size comes from the error norm of the WHOLE batch, as
+    torchdiffeq takes it (``global_step_control``: one small all-reduce per norm; every rank needs at least one row);
+    results then agree across world sizes to the rounding of those norms.  ``global_control=False``: every rank
+    controls its steps from its own rows (agreement to the solver tolerances only)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if (x is None) == (local_x is None):
@@ -129,7 +181,34 @@ def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional:
         rows = local_x.contiguous()
         cond = None if local_conditional is None else local_conditional.contiguous()
     extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if getattr(score_model, "hutch", False) else {}
-    local = score_model.log_prob(rows, conditional=cond, **solver, **extra)
+    with (global_step_control(group) if (global_control and world > 1) else contextlib.nullcontext()):
+        local = score_model.log_prob(rows, conditional=cond, **solver, **extra)
     if not gather:
         return local, (lo, hi)
     return gather_rows(local, n, group) if world > 1 else local
+
+
+def sample_ode_sharded(score_model, n_total: int, dim: int, seed: int = 0, conditional: Optional[torch.Tensor] = None,
+                       group=None, gather: bool = True, local_conditional: Optional[torch.Tensor] = None,
+                       global_control: bool = True, **solver):
+    """``ScoreModel.sample_ode_from_base`` of ``n_total`` base samples over all ranks: the base samples are standard
+    normals of the library's counter-based stream keyed by ``seed`` and the GLOBAL row (``ff_normal_fill``), so every world
+    size transports the same points and a rank only ever touches its rows; one all-gather at the end.  ``**solver`` (atol,
+    rtol, method, options) goes to ``sample_ode_from_base`` unchanged; with an adaptive method (the reference's default)
+    and ``global_control`` the step size comes from the error norm of the whole batch (``global_step_control``)."""
+    from . import _native
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(int(n_total), world, rank)
+    dev = next(score_model.model.parameters()).device
+    z = _native.normal_fill(hi - lo, int(dim), int(seed), lo, dev)
+    cond = None if conditional is None else conditional[lo:hi].contiguous()
+    if local_conditional is not None:
+        if conditional is not None or local_conditional.shape[0] != hi - lo:
+            raise ValueError("local_conditional must hold exactly this rank's rows (and excludes `conditional`)")
+        cond = local_conditional.contiguous()
+    with (global_step_control(group) if (global_control and world > 1) else contextlib.nullcontext()):
+        local, _ = score_model.sample_ode_from_base(z, conditional=cond, **solver)
+    if not gather:
+        return local, (lo, hi)
+    return gather_rows(local, int(n_total), group) if world > 1 else local

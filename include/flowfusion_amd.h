@@ -46,6 +46,7 @@ extern "C" {
 #define FF_ERR_BADARG      -1   /* null pointer / negative size / inconsistent plan        */
 #define FF_ERR_UNSUPPORTED -2   /* no gfx950 kernel instantiation covers this shape        */
 #define FF_ERR_HIP         -3   /* HIP runtime refused the launch (see ff_last_hip_error)  */
+#define FF_ERR_EXCHANGE    -4   /* the caller's ff_adapt_buffers.exchange hook returned non-zero */
 
 #define FF_MAX_SLOTS   7        /* Runge-Kutta stage slots kept on chip (dopri5 + FSAL)    */
 #define FF_MAX_AUX     4        /* auxiliary linear-combination outputs per launch         */
@@ -419,7 +420,19 @@ typedef struct ff_adapt_buffers {
     int32_t n_passes;            /* 1, or the unit-tangent passes of FF_MODE_EXACT                          */
     int32_t pass_first[FF_ADAPT_MAX_PASSES];
     int32_t pass_count[FF_ADAPT_MAX_PASSES];
+    /* Step control over SEVERAL shards of one batch (one process per GPU).  torchdiffeq's norms are over the whole batch
+     * it is handed (one step size for all samples), so when the batch is cut over ranks the sums of squares behind every
+     * norm have to meet: the one exchange step of this path.  With `exchange` set each norm is taken in two launches --
+     * reduce into exchange_sums (FF_EXCHANGE_DOUBLES doubles: FF_NORM_TERMS sums of squares, the count of non-finite
+     * values, FF_NORM_TERMS element counts, one spare), then the controller -- and `exchange(exchange_user, hip_stream)`
+     * is called on the HOST in between: it must ENQUEUE, ordered with hip_stream, an in-place sum of those doubles over
+     * all ranks (an RCCL all-reduce) and return 0; every rank then takes the same decisions and attempts the same number
+     * of steps.  NULL: the norms are over this call's batch. */
+    double* exchange_sums;
+    int (*exchange)(void* user, void* hip_stream);
+    void* exchange_user;
 } ff_adapt_buffers;
+#define FF_EXCHANGE_DOUBLES 8
 
 #define FF_ADAPT_START   1   /* initialise the state, evaluate f(t0, y), choose the first step              */
 #define FF_ADAPT_FINISH  2   /* evaluate the dense output at t_end into out_y / out_lp (a no-op until done)  */

@@ -52,6 +52,7 @@ int main(void)
     OFF(ff_adapt_buffers, out_y); OFF(ff_adapt_buffers, out_lp); OFF(ff_adapt_buffers, state);
     OFF(ff_adapt_buffers, norm_workspace); OFF(ff_adapt_buffers, norm_only); OFF(ff_adapt_buffers, norm_only_n);
     OFF(ff_adapt_buffers, n_passes); OFF(ff_adapt_buffers, pass_first); OFF(ff_adapt_buffers, pass_count);
+    OFF(ff_adapt_buffers, exchange_sums); OFF(ff_adapt_buffers, exchange); OFF(ff_adapt_buffers, exchange_user);
 
     /* plan + packed size for BASELINE config 2's network, from C */
     const int hidden[4] = {256, 256, 256, 256};

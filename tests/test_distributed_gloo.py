@@ -116,3 +116,72 @@ def test_log_prob_sharded_over_gloo(world, n):
         assert p.exitcode == 0
     results = dict(q.get(timeout=5) for _ in range(world))
     assert results == {r: True for r in range(world)}
+
+
+def _global_control_worker(rank, world, port, q):
+    """An adaptive dopri5 solve (host controller on the CPU kernel-semantics emulator) of a batch cut over the ranks: under
+    distributed.global_step_control every rank walks the steps of the whole-batch solve."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowfusion_amd import _native, adaptive
+        from flowfusion_amd import diffusion as D
+        from flowfusion_amd.distributed import global_step_control
+        from flowfusion_amd.fused import MODE_HUTCH
+        from tests import _emulator as E
+        torch.manual_seed(3)
+        sm = D.ScoreModel(D.MLP(3, 0, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+        net = sm._net()
+        n = 11
+        x = torch.randn(n, 3)
+        x[:4] *= 6.0                                        # the first shard carries the largest errors
+        e = torch.sign(torch.randn(n, 3))
+        eps = float(torch.tensor(float(sm.sde.epsilon), dtype=torch.float32))
+        sched = lambda tr: sm._schedule(tr, "ode")[:3]
+        plan = _native.plan_words(net.plan(MODE_HUTCH))
+        wpack = net.wpack("cpu", MODE_HUTCH)
+
+        def solve(lo, hi):
+            pr = e[lo:hi]
+            launcher = lambda y, k1, kl1, lp0, etab, n_aux, first, count: E.emulate_step(
+                plan, wpack, etab, y, None, pr, k1, kl1, lp0, MODE_HUTCH, n_aux, first, count)
+            step = net.make_step(sched, 1.0, MODE_HUTCH, "cpu", probe=pr, launcher=launcher)
+            solver = adaptive.Dopri5(step, True, 1e-5, 1e-5, {"min_step": 1e-9})
+            y, lp = solver.integrate(eps, 1.0, x[lo:hi], torch.zeros(hi - lo))
+            return y, lp, (solver.n_attempts, solver.n_accepted)
+
+        lo, hi = shard_bounds(n, world, rank)
+        yw, lw, sw = solve(0, n)
+        ya, la, sa = solve(lo, hi)
+        with global_step_control():
+            yg, lg, sg = solve(lo, hi)
+        err = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1.0))
+        q.put((rank, {"whole": sw, "alone": sa, "global": sg,
+                      "err_global": max(err(yg, yw[lo:hi]), err(lg, lw[lo:hi])),
+                      "err_alone": max(err(ya, yw[lo:hi]), err(la, lw[lo:hi]))}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_step_control_over_gloo(built_library):
+    """The one exchange step of the path (an adaptive solve's batch-global error norm) on the CPU: two ranks, the host step
+    controller on the emulated kernels.  Under the context both ranks attempt / accept the whole-batch solve's steps and
+    reproduce its rows to the rounding of the norms (fp32 mean of squares on one rank vs float64 sums that met: the step
+    sizes differ in their last bits)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_global_control_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert set(results) == {0, 1}
+    for r, c in results.items():
+        assert tuple(c["global"]) == tuple(c["whole"]), (r, c)
+        assert c["err_global"] < 2e-5, (r, c)
+        assert c["err_alone"] < 5e-3, (r, c)
+    assert any(tuple(c["alone"]) != tuple(c["whole"]) or c["err_alone"] > 100 * max(c["err_global"], 1e-12) for c in results.values())

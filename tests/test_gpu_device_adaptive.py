@@ -410,3 +410,75 @@ def test_rows_naming_a_slot_off_chip_are_refused():
     assert rc == _native.FF_ERR_UNSUPPORTED
     rc, _ = _raw_launch(sw, xw, tw, stage_slots=4)
     assert rc == 0
+
+
+def test_global_step_control_over_ranks(tmp_path):
+    """distributed.global_step_control: torchdiffeq's step size comes from a norm over the WHOLE batch, so an adaptive
+    solve sharded over ranks has one real exchange step -- the sums of squares behind every norm (ff_adapt_buffers.exchange:
+    reduce kernel, all-reduce of 8 doubles enqueued by the host hook, controller kernel).  Three ranks on cuda:0 over gloo
+    (RCCL refuses several ranks on one device; a fresh child process tree): under the context every rank attempts and
+    accepts exactly the steps of the whole-batch solve and its rows agree with that solve to rounding, for the score
+    model's sampler, its exact-trace log_prob, a flow and the host step controller; without it the ranks' own norms
+    give different step sequences (the shards are built to differ)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    W = 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(W), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tests" / "_global_control_worker.py")]
+    import os
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root),
+                       env=dict(os.environ, FF_RESULT_DIR=str(tmp_path)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    recs = [json.loads(p.read_text()) for p in sorted(tmp_path.glob("rank*.json"))]
+    assert sorted(x["rank"] for x in recs) == list(range(W))
+    differs = 0
+    for rec in recs:
+        assert rec["empty_raises"] is True
+        for name in ("sample_ve_2d", "log_prob_ve_2d_exact", "flow_sample_8d", "sample_ve_2d_host_controller"):
+            c = rec[name]
+            for k in ("attempts", "accepted"):
+                assert c["global"][k] == c["whole"][k], (name, rec["rank"], c)
+            assert c["err_global"] < 2e-5, (name, rec["rank"], c)
+            assert c["err_alone"] < 2e-3, (name, rec["rank"], c)     # a shard on its own: other steps, same answer to the solver tolerances
+            differs += c["alone"]["attempts"] != c["whole"]["attempts"] or c["err_alone"] > 10 * max(c["err_global"], 1e-7)
+        assert rec["sample_ode_sharded"]["span_ok"] and rec["sample_ode_sharded"]["err"] < 2e-5, rec
+        lh = rec["log_prob_sharded_hutch"]
+        assert lh["span_ok"] and lh["same_steps"] and lh["err"] < 2e-5, lh
+    assert differs > 0        # the exchange is what made the step sequences equal
+
+
+def test_cooperative_twin_is_deterministic_when_the_card_is_shared(tmp_path):
+    """Regression (round 3): the four wavefronts of a cooperative-twin workgroup share the Runge-Kutta stage slots; a
+    wavefront that started late zero-filled them AFTER another had stored the caller's first stage (k1_in, every adaptive
+    attempt) and before that one read it back.  Alone on the card the wavefronts start together and nothing shows; with
+    three processes on the card nearly every repeat of an adaptive solve gave another step sequence.  Three processes
+    repeat one default-argument log_prob at a cooperative-twin batch (3001 x 16-d), both controllers: one fingerprint
+    each, the same in every process."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    W = 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(W), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tests" / "_contention_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root),
+                       env=dict(os.environ, FF_RESULT_DIR=str(tmp_path)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    recs = [json.loads(p.read_text()) for p in sorted(tmp_path.glob("contention*.json"))]
+    assert len(recs) == W
+    for rec in recs:
+        assert len(rec) == 2 and sorted(rec.values()) == [25, 25], rec          # one fingerprint per controller
+        assert rec.keys() == recs[0].keys()
