@@ -617,6 +617,10 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #endif
 
     bool bad_slot = false;
+    // Cooperative twin: the exchange buffer of the NEXT activation hand-over.  It alternates over the whole launch, not per
+    // evaluation: with an odd number of hidden layers a per-evaluation count would end one evaluation and start the next on
+    // the same buffer, with a single barrier between a slow wavefront's reads of the old contents and a fast one's stores.
+    [[maybe_unused]] int xbuf = 0;
     for (int e = 0; e < args.n_evals; ++e) {
         const int row_byte = e * args.etab_stride * 4;
         HdrPtr hdr = (HdrPtr)(args.etab + (size_t)e * args.etab_stride);
@@ -752,7 +756,6 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                 });
             };
             BlockAcc<TILE> cacc[NBW];
-            int xbuf = 0;
             // layer 1
 #pragma unroll
             for (int j = 0; j < NBW; ++j) cacc[j] = load_bias_acc<TILE>(ts, q16b, c1_byte + (ob0 + j) * 128);
@@ -774,6 +777,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
 #pragma unroll
             for (int o = 0; o < NOB_OUT; ++o) obias[o] = load_bias<TILE>(ws, q16b, out_bias_byte + o * 128);
             coop_exchange(cacc, xbuf);
+            xbuf ^= 1;
             // output layer: every wavefront computes all of it (a handful of rows; no exchange, and the same chain as the
             // one-wavefront kernel); the ring moves on to layer 1 of the next evaluation
             BlockAcc<TILE> oacc[NOB_OUT];

@@ -26,6 +26,15 @@ def main():
             key = f"{ctrl} {hm.last_solver_stats['attempts']} {hm.last_solver_stats['accepted']} {float(r.double().sum())!r}"
             seen[key] = seen.get(key, 0) + 1
     os.environ.pop("FF_HOST_CONTROLLER", None)
+    # an odd number of hidden layers (the notebook's 3 x 128): the exchange buffers of consecutive evaluations
+    from flowfusion_amd.diffusion import VESDE
+    torch.manual_seed(0)
+    nb = ScoreModel(MLP(2, 0, 8, [128] * 3), VESDE()).eval().to(dev)
+    z = torch.randn(1000, 2, device=dev) * 3
+    for _ in range(25):
+        r, _ = nb.sample_ode_from_base(z)
+        key = f"odd {nb.last_solver_stats['attempts']} {nb.last_solver_stats['accepted']} {float(r.double().sum())!r}"
+        seen[key] = seen.get(key, 0) + 1
     with open(os.path.join(os.environ["FF_RESULT_DIR"], f"contention{rank}.json"), "w") as fh:
         json.dump(seen, fh)
 

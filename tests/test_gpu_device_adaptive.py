@@ -455,12 +455,15 @@ def test_global_step_control_over_ranks(tmp_path):
 
 
 def test_cooperative_twin_is_deterministic_when_the_card_is_shared(tmp_path):
-    """Regression (round 3): the four wavefronts of a cooperative-twin workgroup share the Runge-Kutta stage slots; a
-    wavefront that started late zero-filled them AFTER another had stored the caller's first stage (k1_in, every adaptive
-    attempt) and before that one read it back.  Alone on the card the wavefronts start together and nothing shows; with
-    three processes on the card nearly every repeat of an adaptive solve gave another step sequence.  Three processes
-    repeat one default-argument log_prob at a cooperative-twin batch (3001 x 16-d), both controllers: one fingerprint
-    each, the same in every process."""
+    """Regression (round 3), two races of the cooperative twin that only show when its wavefronts do not run in step:
+    (1) the four wavefronts of a workgroup share the Runge-Kutta stage slots, and a wavefront that started late
+    zero-filled them AFTER another had stored the caller's first stage (k1_in, every adaptive attempt) and before that one
+    read it back; (2) the activation exchange alternated its two LDS buffers per evaluation, so with an odd number of
+    hidden layers one evaluation ended and the next began on the same buffer, one barrier apart.  Alone on the card the
+    wavefronts start and run together and nothing shows; with three processes on the card nearly every repeat of an
+    adaptive solve gave another step sequence.  Three processes repeat a default-argument log_prob at a cooperative-twin
+    batch (3001 x 16-d, both controllers) and the notebook model's sampler (3 x 128: odd): one fingerprint each, the same
+    in every process."""
     import json
     import os
     import socket
@@ -480,5 +483,5 @@ def test_cooperative_twin_is_deterministic_when_the_card_is_shared(tmp_path):
     recs = [json.loads(p.read_text()) for p in sorted(tmp_path.glob("contention*.json"))]
     assert len(recs) == W
     for rec in recs:
-        assert len(rec) == 2 and sorted(rec.values()) == [25, 25], rec          # one fingerprint per controller
+        assert len(rec) == 3 and sorted(rec.values()) == [25, 25, 25], rec      # one fingerprint per case
         assert rec.keys() == recs[0].keys()
