@@ -1,11 +1,13 @@
 """Multi-GPU execution of the sampling / log-density path: one process per GPU, batch sharding,
-one collective at the end.
+one collective at the end (adaptive solves: plus the exchange of their error norms, `global_step_control`).
 
 The reference is single-process (no torch.distributed anywhere in flowfusion/).  Samples are
 independent -- nothing on the path couples two rows of the batch -- so the batch axis is cut into
 contiguous, balanced shards, every rank integrates its shard with the fused kernel (weights and the
 evaluation table are a few MB and simply replicated), and the results meet in a single RCCL
-all-gather over xGMI (backend "nccl" is RCCL on ROCm).  No other collective is used.
+all-gather over xGMI (backend "nccl" is RCCL on ROCm).  Fixed-grid solves use no other collective.  Adaptive solves have
+one real exchange step: torchdiffeq chooses ONE step size for the whole batch from a norm over all of it, so the sums of
+squares behind each norm are all-reduced (8 doubles) when a batch is cut over ranks -- `global_step_control`.
 """
 from __future__ import annotations
 

@@ -45,8 +45,27 @@ for B in (700, 3001, 40000):
         sm.precision = prec
         stress(f"16d vp rk4 sample {prec} B={B}", lambda: sm.sample_ode_from_base(x, method="rk4", options=o)[0])
     sm.precision = "f32"
+# the split-precision family under the adaptive driver and with tangents
+for prec in ("bf16x2", "bf16x3"):
+    sm.precision = prec
+    for B in (700, 40000):
+        x = torch.randn(B, 16, device=dev) * 0.8
+        stress(f"16d vp adaptive sample {prec} B={B}", lambda: sm.sample_ode_from_base(x * 0.5)[0], reps=REPS // 2)
+        if prec == "bf16x2":
+            sm.hutch = True
+            stress(f"16d vp rk4 hutch log_prob {prec} B={B}", lambda: sm.log_prob(x, method="rk4", options=o, probe="philox", seed=3), reps=REPS // 2)
+            stress(f"16d vp adaptive hutch log_prob {prec} B={B}", lambda: sm.log_prob(x, probe="philox", seed=3), reps=REPS // 2)
+            sm.hutch = False
+            if B == 700:
+                stress(f"16d vp adaptive exact log_prob {prec} B={B}", lambda: sm.log_prob(x), reps=REPS // 4)
+sm.precision = "f32"
 torch.manual_seed(0)
 nb = ScoreModel(MLP(2, 0, 8, [128] * 3), VESDE()).eval().to(dev)
+nb.precision = "bf16x2"
+z2 = torch.randn(20000, 2, device=dev) * 3
+stress("2d ve 3x128 adaptive sample bf16x2 B=20000", lambda: nb.sample_ode_from_base(z2)[0], reps=REPS // 2)
+stress("2d ve 3x128 adaptive exact log_prob bf16x2 B=20000", lambda: nb.log_prob(z2 * 0.1), reps=REPS // 4)
+nb.precision = "f32"
 for B in (1000, 50000):
     z = torch.randn(B, 2, device=dev) * 3
     p = torch.randn(B, 2, device=dev) * 0.5
