@@ -485,3 +485,41 @@ def test_cooperative_twin_is_deterministic_when_the_card_is_shared(tmp_path):
     for rec in recs:
         assert len(rec) == 3 and sorted(rec.values()) == [25, 25, 25], rec      # one fingerprint per case
         assert rec.keys() == recs[0].keys()
+
+
+def test_two_host_threads_on_two_streams():
+    """include/flowfusion_amd.h: "safe to call from several host threads on different streams".  Two threads, each on a
+    stream of its own, repeat different default-argument solves at the same time (the norm workspace is per stream, the work
+    buffers per call); every result equals the one the solve gives alone on the default stream, bit for bit."""
+    import threading
+    from flowfusion_amd.diffusion import MLP, VESDE, VPSDE, ScoreModel
+    torch.manual_seed(0)
+    a = ScoreModel(MLP(2, 0, 8, [128] * 3), VESDE()).eval().to(DEV)
+    torch.manual_seed(1)
+    b = ScoreModel(MLP(16, 0, 8, [256] * 4), VPSDE(), no_sigma=True, hutchinson=True).eval().to(DEV)
+    za = torch.randn(5000, 2, device=DEV) * 3
+    xb = torch.randn(3001, 16, device=DEV) * 0.8
+    ref_a, _ = a.sample_ode_from_base(za)
+    ref_b = b.log_prob(xb, probe="philox", seed=4)
+    torch.cuda.synchronize()
+    bad, errors = [], []
+
+    def work(fn, ref, tag):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for i in range(15):
+                    r = fn()
+                    s.synchronize()
+                    if not torch.equal(r, ref):
+                        bad.append((tag, i))
+        except Exception as exc:          # noqa: BLE001
+            errors.append((tag, repr(exc)))
+
+    ts = [threading.Thread(target=work, args=(lambda: a.sample_ode_from_base(za)[0], ref_a, "sample")),
+          threading.Thread(target=work, args=(lambda: b.log_prob(xb, probe="philox", seed=4), ref_b, "log_prob"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errors and not bad, (errors, bad)
