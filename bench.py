@@ -498,6 +498,67 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
     return recs, bool(flag.item() == 1.0)
 
 
+def adaptive_exchange_extra(device, world, rank, dist, backend, rows):
+    """N > 1: the one exchange step of the path.  The headline model's default-argument log_prob (adaptive dopri5,
+    Hutchinson probe keyed by the global row), `rows` points cut over the ranks, step size from the error norm of the WHOLE
+    batch as torchdiffeq takes it (distributed.global_step_control: the sums of squares behind every norm are all-reduced
+    between the reduction and the controller kernel).  Every rank also solves the whole batch alone (it fits one GPU) and
+    compares: same attempt / accept counts, its rows within rounding of the whole-batch solve."""
+    from flowfusion_amd import _native
+    from flowfusion_amd.distributed import log_prob_sharded, shard_bounds
+    gather_dev = device if backend == "nccl" else torch.device("cpu")
+    sm = build_model(device)
+    sm.hutch = True
+    lo, hi = shard_bounds(rows, world, rank)
+    x = _native.normal_fill(rows, DIM, 4321, 0, device, scale=0.8)
+    mine = x[lo:hi].contiguous()
+    log_prob_sharded(sm, local_x=mine, n_total=rows, seed=5, gather=False)                       # warm-up (same collectives on all ranks)
+    dist.barrier()
+    (lp, _), wall, _ = _timed(lambda: log_prob_sharded(sm, local_x=mine, n_total=rows, seed=5, gather=False), device)
+    st = dict(sm.last_solver_stats)
+    (alone, _), wall_alone, _ = _timed(lambda: log_prob_sharded(sm, local_x=mine, n_total=rows, seed=5, gather=False,
+                                                                global_control=False), device)
+    st_alone = dict(sm.last_solver_stats)
+    whole, wall_whole, _ = _timed(lambda: sm.log_prob(x, probe="philox", seed=5), device)
+    st_whole = dict(sm.last_solver_stats)
+    rel = lambda a, b: float(((a - b).abs() / b.abs().clamp_min(1.0)).max())
+    vals = torch.tensor([1e3 * wall, 1e3 * wall_alone, st["attempts"], st["accepted"], st_alone["attempts"],
+                         rel(lp, whole[lo:hi]), rel(alone, whole[lo:hi])], device=gather_dev, dtype=torch.float64)
+    allr = [torch.zeros_like(vals) for _ in range(world)]
+    dist.all_gather(allr, vals)
+    col = lambda i: [float(t[i]) for t in allr]
+    same = all(int(a) == st_whole["attempts"] for a in col(2)) and all(int(a) == st_whole["accepted"] for a in col(3))
+    return {"workload": f"default-argument log_prob (adaptive dopri5, Hutchinson), 16-dim VP-SDE 4x256, {rows} points sharded over "
+                        f"{world} GPUs with whole-batch step control (one all-reduce of 8 doubles per error norm)",
+            "value": rows / (max(col(0)) * 1e-3), "unit": "log-probs/s", "dtype": "f32",
+            "whole_batch_on_one_gpu": {"wall_ms": 1e3 * wall_whole, **st_whole},
+            "per_rank": {"wall_ms": col(0), "wall_ms_own_norm_only": col(1), "attempts": col(2), "accepted": col(3),
+                         "attempts_own_norm_only": col(4), "max_rel_diff_vs_whole_batch_solve": col(5),
+                         "max_rel_diff_vs_whole_batch_solve_own_norm_only": col(6)},
+            "steps_equal_whole_batch_solve_on_all_ranks": bool(same)}
+
+
+def run_guarded(fn, seconds, device=None):
+    """fn() in a daemon thread: (result, None), or (None, reason) after an exception or `seconds` without an answer -- a
+    collective that never completes must not take the line this run has already measured with it."""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            if device is not None:
+                torch.cuda.set_device(device)          # (the current device is per thread)
+            box["r"] = fn()
+        except Exception as exc:          # noqa: BLE001
+            box["e"] = repr(exc)
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, f"no answer within {seconds} s"
+    return box.get("r"), box.get("e")
+
+
 def streaming_helpers(device):
     """The memory-bound kernels beside the fused integrator (csrc/ff_aux.hip: Runge-Kutta stage algebra of the module path,
     error norms of an adaptive step, the counter-based prior draw) at solver-sized arrays (2^22 x 16 fp32): algorithmic
@@ -556,6 +617,8 @@ def main():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--c4-rows", type=int, default=1 << 22, help="N > 1: rows of BASELINE configs[3] over the node")
     ap.add_argument("--c5-rows", type=int, default=1 << 20, help="N > 1: rows of BASELINE configs[4] over the node")
+    ap.add_argument("--adaptive-rows", type=int, default=1 << 18,
+                    help="N > 1: points of the default-argument (adaptive) log_prob solved with whole-batch step control (0 = skip)")
     ap.add_argument("--c3-rows", type=int, default=1 << 20, help="N > 1: rows of BASELINE configs[2] (log_prob) over the node")
     ap.add_argument("--c3-steps", type=int, default=N_STEPS, help="N > 1: RK4 steps of configs[2]")
     ap.add_argument("--c4-steps", type=int, default=200, help="N > 1: fixed steps of configs[3] (rehearsals shorten it)")
@@ -667,6 +730,15 @@ def main():
         flag = torch.tensor([1.0 if rank_invariant else 0.0], device=gather_dev, dtype=torch.float64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         rank_invariant = bool(flag.item() == 1.0)
+        # last of all, guarded: the adaptive path's exchange step has never run under RCCL before a node runs this line
+        hung = False
+        if args.extras and args.adaptive_rows > 0:
+            res, why = run_guarded(lambda: adaptive_exchange_extra(device, world, rank, dist, args.backend, args.adaptive_rows),
+                                   300, device)
+            hung = res is None and why is not None and why.startswith("no answer")
+            entry = res if res is not None else {"workload": "default-argument log_prob sharded with whole-batch step control",
+                                                 "error": why}
+            sharded = (sharded or []) + [entry]
 
     if rank == 0:
         print(f"[bench] timed region {elapsed:.3f} s, kernel avg {kernel_ms_avg:.1f} ms", file=sys.stderr, flush=True)
@@ -790,6 +862,9 @@ def main():
             out["streaming_helpers"] = streaming_helpers(device)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if hung:                 # a rank stuck in a collective cannot tear the group down: the line is out, leave
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -359,7 +359,7 @@ def test_bench_four_ranks_rehearsal_on_one_gpu():
     """The driver launches bench.py for N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`.  No second
     GPU exists here, so the multi-rank branch (process group, sharded solve, the all-gather inside the timed region,
     max-over-ranks timing, per-rank report, the sharded BASELINE configs[2] / [3] / [4] extras with their all-gathers, the
-    rank-invariance checks) is rehearsed with FOUR ranks on cuda:0 over gloo, in a fresh child process tree (started
+    rank-invariance checks, the adaptive path's whole-batch step control) is rehearsed with FOUR ranks on cuda:0 over gloo, in a fresh child process tree (started
     before this process hands anything to it; nothing is exec'ed after GPU init).  Four, not eight: a GPU box admits
     at most six processes on its card, and the N = 8 launch is the driver's; nothing in the branch depends on the world
     size beyond `shard_bounds`, which tests/test_distributed_gloo.py runs at world 8 on the CPU."""
@@ -376,7 +376,7 @@ def test_bench_four_ranks_rehearsal_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(W), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(root / "bench.py"), "--gpus", str(W), "--backend", "gloo", "--single-device",
            "--steps", "1", "--warmup", "0", "--cpu-batch", "0", "--batch", "16384",
-           "--c3-rows", "6100", "--c3-steps", "6",
+           "--c3-rows", "6100", "--c3-steps", "6", "--adaptive-rows", "3001",
            "--c4-rows", "4100", "--c4-steps", "8", "--c5-rows", "8200", "--c5-steps", "24"]       # ragged shards on purpose
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root))
     assert r.returncode == 0, r.stderr[-3000:]
@@ -389,8 +389,11 @@ def test_bench_four_ranks_rehearsal_on_one_gpu():
     assert rec["rank_invariant"] is True and rec["host_threads_per_rank"] >= 1
     assert "cpu_baseline" not in rec
     extras = rec["extra_configs"]
-    assert len(extras) == 3 and all(f"configs[{i + 2}]" in e["workload"] for i, e in enumerate(extras))
-    for e, rows in zip(extras, (6100, 4100, 8200)):
+    assert len(extras) == 4 and all(f"configs[{i + 2}]" in e["workload"] for i, e in enumerate(extras[:3]))
+    ad = extras[3]                                                      # the adaptive path's exchange step
+    assert "error" not in ad and ad["steps_equal_whole_batch_solve_on_all_ranks"] is True, ad
+    assert len(ad["per_rank"]["attempts"]) == W and max(ad["per_rank"]["max_rel_diff_vs_whole_batch_solve"]) < 2e-5, ad
+    for e, rows in zip(extras[:3], (6100, 4100, 8200)):
         assert e["rank_invariant"] is True and e["value"] > 0
         for k in ("wall_ms", "kernel_ms", "allgather_ms"):
             assert len(e["per_rank"][k]) == W and all(v >= 0 for v in e["per_rank"][k])
