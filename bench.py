@@ -613,6 +613,8 @@ def main():
                     help="collective backend for N > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the one-launch timings of BASELINE configs 3, 4, 5 (N = 1 only)")
+    ap.add_argument("--group-of-one", action="store_true",
+                    help="rehearsal: run the N > 1 branch with a one-rank process group (needs --gpus 1)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--c4-rows", type=int, default=1 << 22, help="N > 1: rows of BASELINE configs[3] over the node")
@@ -626,6 +628,9 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on one GPU: take the multi-rank branch with a process group of ONE rank (RCCL refuses two ranks on one
+    # device), so that every collective call of that branch has run under RCCL before a node runs it
+    multi = world > 1 or args.group_of_one
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -639,9 +644,10 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")      # (torch.distributed.run sets both; the one-rank rehearsal may not)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -661,7 +667,7 @@ def main():
     from flowfusion_amd import _native
     z = _native.normal_fill(B, DIM, 1234, rank * B, device)
     gather_dev = device if args.backend == "nccl" else torch.device("cpu")
-    gathered = torch.empty(world * B, DIM, device=gather_dev) if world > 1 else None
+    gathered = torch.empty(world * B, DIM, device=gather_dev) if multi else None
 
     def step(events=None):
         # HIP events on the stream the kernel is launched on (torch's current stream) bracket the fused launch
@@ -671,14 +677,14 @@ def main():
         x, _ = sm.sample_ode_from_base(z, method="rk4", options=opts)
         if events is not None:
             events[1].record()
-        if world > 1:      # the single collective of the path: all shards meet on every rank
+        if multi:      # the single collective of the path: all shards meet on every rank
             dist.all_gather_into_tensor(gathered, x if args.backend == "nccl" else x.cpu())
             if events is not None:
                 events[2].record()
         return x
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -695,7 +701,7 @@ def main():
         x = step(ev[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], device=gather_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -704,7 +710,7 @@ def main():
     kernel_ms = sorted(s.elapsed_time(e) for s, e, _ in ev)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     per_rank = None
-    if world > 1:
+    if multi:
         # what each rank spent in its kernel and in the collective (gloo rehearsal: the collective runs on the host
         # after a device-to-host copy, the events then only bracket that copy's enqueue)
         gather_ms_avg = sum(e.elapsed_time(g) for _, e, g in ev) / len(ev) if args.backend == "nccl" else float("nan")
@@ -717,7 +723,7 @@ def main():
     head, _ = sm.sample_ode_from_base(z[:256].contiguous(), method="rk4", options=opts)
     rank_invariant = bool(torch.equal(head, x[:256]))
     sharded = None
-    if world > 1:
+    if multi:
         rank_invariant &= bool(torch.equal(gathered[rank * B: rank * B + 256].to(device), x[:256]))
         if args.extras:
             try:
@@ -762,7 +768,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 16-dim VP-SDE score model, MLP 4x256, 100-step RK4 "
                                    "probability-flow ODE sampler (torchdiffeq rk4 = 3/8 rule, %d evals)" % n_evals,
                        "batch_per_gpu": B, "global_batch": world * B, "state_dim": DIM, "hidden": UNITS,
-                       "sharding": f"batch x{world}, one RCCL all-gather per step" if world > 1 else "single GPU"},
+                       "sharding": f"batch x{world}, one RCCL all-gather per step" if multi else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "kernel": kernel_name, "kernel_ms_avg": kernel_ms_avg,
@@ -788,7 +794,7 @@ def main():
                     "file": "profiles/hbm_traffic.json", "from": tf.get("source"), "commit": tf.get("commit"),
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile_round.sh), "
                             "not measured by this run"}
-        if args.cpu_batch > 0 and world == 1:      # CPU baseline and oracle parity: rank 0 of the 1-GPU run only
+        if args.cpu_batch > 0 and not multi:      # CPU baseline and oracle parity: rank 0 of the 1-GPU run only
             ref, zc, cb = cpu_baseline(sm, args.cpu_batch, opts)
             out["cpu_baseline"] = cb
             # parity of the timed configuration: GPU vs oracle on the same base samples
@@ -829,7 +835,7 @@ def main():
             _, _, cb1 = cpu_baseline(sm, 2048, opts, budget_s=10.0, threads=1)
             out["cpu_baseline_1thread"] = cb1
             torch.set_num_threads(host_threads)
-        if args.extras and world == 1:
+        if args.extras and not multi:
             out["split_precision_record"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x3")
             out["split_precision_record_bf16x2"] = split_precision_record(device, z, opts, args.steps, 1, x, "bf16x2")
             if args.cpu_batch > 0:
@@ -861,7 +867,7 @@ def main():
             out["extra_configs"] = extra_configs(device)
             out["streaming_helpers"] = streaming_helpers(device)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         if hung:                 # a rank stuck in a collective cannot tear the group down: the line is out, leave
             sys.stdout.flush()
             os._exit(0)

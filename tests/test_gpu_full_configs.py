@@ -398,3 +398,59 @@ def test_bench_four_ranks_rehearsal_on_one_gpu():
         for k in ("wall_ms", "kernel_ms", "allgather_ms"):
             assert len(e["per_rank"][k]) == W and all(v >= 0 for v in e["per_rank"][k])
         assert e["rows_per_rank"] == -(-rows // W)                      # rank 0 holds the larger share of a ragged split
+
+
+def test_rccl_single_rank(tmp_path):
+    """RCCL itself, as far as one GPU allows: a one-rank "nccl" process group in a fresh child process runs every collective
+    the multi-GPU code issues and the adaptive path's exchange hook (the all-reduce enqueued from the C driver's callback
+    between the reduction launch and the controller launch) -- see tests/_rccl_worker.py."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, FF_RESULT_DIR=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(root / "tests" / "_rccl_worker.py")], capture_output=True, text=True, timeout=600,
+                       cwd=str(root), env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads((tmp_path / "rccl.json").read_text())
+    assert rec and all(rec.values()), rec
+
+
+def test_bench_multi_rank_branch_under_rccl_with_one_rank():
+    """bench.py's N > 1 branch with backend "nccl" (RCCL), as far as one GPU allows: `--group-of-one` takes that branch with a
+    one-rank process group, so its device-side collectives (the all-gather inside the timed region with HIP events around
+    it, the float64 all-reduces / all-gathers of the per-rank report, the sharded extras, the guarded adaptive extra) have
+    all run under RCCL before a node runs them."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--group-of-one", "--steps", "2", "--warmup", "1",
+           "--cpu-batch", "0", "--batch", "16384", "--c3-rows", "6100", "--c3-steps", "6", "--adaptive-rows", "3001",
+           "--c4-rows", "4100", "--c4-steps", "8", "--c5-rows", "8200", "--c5-steps", "24"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["rank_invariant"] is True and rec["value"] > 0
+    assert len(rec["per_rank"]["kernel_ms_avg"]) == 1 and rec["per_rank"]["allgather_ms_avg"][0] >= 0
+    extras = rec["extra_configs"]
+    assert len(extras) == 4 and all("error" not in e for e in extras), extras
+    assert all(e["rank_invariant"] for e in extras[:3]) and extras[3]["steps_equal_whole_batch_solve_on_all_ranks"] is True
