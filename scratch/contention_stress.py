@@ -94,6 +94,15 @@ for units in ([128], [256], [64, 64, 64], [256] * 3, [128] * 5):          # odd 
     tag = "x".join(str(u) for u in units)
     stress(f"4d ve {tag} adaptive sample B=800", lambda: g.sample_ode_from_base(z)[0], reps=REPS // 2)
     stress(f"4d ve {tag} rk4 exact log_prob B=800", lambda: g.log_prob(z * 0.1, method="rk4", options={"step_size": 0.05}), reps=REPS // 2)
+# the estimators' Jacobian output (jac_out / jac_all: written by wavefront 0 of a cooperative workgroup)
+for kw in ({"hutchpp": True, "hpp_rank": 2, "hpp_vecs": 2}, {"xtrace": True, "xt_vecs": 3}):
+    torch.manual_seed(7)
+    em = ScoreModel(MLP(8, 0, 8, [128] * 3), VESDE(), **kw).eval().to(dev)
+    xe = torch.randn(600, 8, device=dev) * 0.3
+    def est():
+        torch.manual_seed(11)                 # the probes are drawn with torch's generator
+        return em.log_prob(xe, method="rk4", options={"step_size": 0.1})
+    stress(f"8d ve 3x128 {list(kw)[0]} rk4 log_prob B=600", est, reps=REPS // 4)
 fw = Fm.ODEFlow(8, [1024, 1024]).to(dev).eval()            # the wide catch-all (cooperative at every batch)
 xT = torch.randn(500, 8, device=dev)
 stress("8d flow 2x1024 (wide) adaptive sample B=500", lambda: fw.sample(xT), reps=REPS // 2)
