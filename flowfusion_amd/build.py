@@ -47,10 +47,12 @@ INSTANCES = [
     for c in (0, 8)
     for t in (0, 1)
 ] + [
-    # 128-wide networks on the 16-column tile, two wavefronts per SIMD (round 3: the reference's own notebook networks are
-    # 3x128; the 32-column kernels ran them at ~65 % of the MFMA rate with one wavefront per SIMD -- measured
-    # scratch/tile16_h128.py: +8..12 % at 2^20 samples, notebook log_prob 19.1 -> 16.7 ms)
-    (16, 128, 4, c, t, 2, 8, 0) for c in (0, 4) for t in (0, 1)
+    # 128-wide networks on the 16-column tile (round 3: the reference's own notebook networks are 3x128; the 32-column
+    # kernels ran them at ~65 % of the MFMA rate with one wavefront per SIMD -- measured scratch/tile16_h128.py: +8..12 %
+    # at 2^20 samples with two wavefronts per SIMD, notebook log_prob 19.1 -> 16.7 ms).  THREE wavefronts per SIMD with four
+    # chunks in flight (149 registers, no spill; eight chunks spill at the 168-register cap): another +1..5 %, 16.1 ms --
+    # at this width the activations' VALU time is half of the MFMA time, and a third wavefront hides more of it
+    (16, 128, 4, c, t, 3, 4, 0) for c in (0, 4) for t in (0, 1)
 ] + [
     # Two wavefronts per SIMD: with 16 samples per wavefront a 256-wide network needs only 64 + 64
     # activation/accumulator registers, so two wavefronts share a SIMD and one's VALU work (SiLU,
