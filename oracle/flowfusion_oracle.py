@@ -18,7 +18,9 @@ Pinning:
     restates torchdiffeq's published fixed-grid algorithm from memory of that package --
     PARITY UNPINNED for the stepper itself.  It is anchored by (a) hybrid vectors: this stepper
     driving the reference's own RHS (tests/golden), (b) known-answer tests with analytic scores
-    (convergence order), see tests/test_oracle_*.py.
+    (convergence order), see tests/test_oracle_*.py, (c) scipy (in this image): its RK45 / RK23 hold the
+    same tableaux (numbers equal to 1e-16) and the same Hairer step control -- given this file's error
+    weights, scipy's stepper and ``odeint_dopri5`` take the same steps (tests/test_oracle_known_answers.py).
 """
 from __future__ import annotations
 
@@ -576,7 +578,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     y, f = tuple(y0), f0
     t_lo = t_hi = t0
     last = None
-    last_adaptive_stats.update(attempts=0, accepted=0)
+    last_adaptive_stats.update(attempts=0, accepted=0, steps=[])      # steps: (t, dt, error ratio, accepted) per attempt
     n_steps = 0
     while t[-1] > t_hi:
         assert n_steps < max_num_steps, f"max_num_steps exceeded ({n_steps}>={max_num_steps})"
@@ -602,6 +604,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
             accept = False
         if dt <= min_step:
             accept = True
+        last_adaptive_stats["steps"].append((float(ta), float(dt), float(ratio), accept))
         if accept:
             ymid = tuple(a + b for a, b in zip(y, comb(ks, C_MID, dt32)))
             last = (ta, tb, dt32, y, y1, ymid, f, f1)

@@ -256,3 +256,69 @@ def test_dopri8_tableau_is_what_it_claims_to_be():
     assert 7.5 < np.log2(solve(b8, 4) / solve(b8, 8)) < 8.8 and 7.5 < np.log2(solve(b8, 8) / solve(b8, 16)) < 8.8
     assert 6.5 < np.log2(solve(b7, 4) / solve(b7, 8)) < 9.0
     assert solve(b8, 16) < 1e-12
+
+
+@pytest.mark.parametrize("method", ["dopri5", "bosh3"])
+def test_step_control_law_against_scipy(method):
+    """An executable third-party anchor for the part of the adaptive solver the tableau pins cannot reach.  torchdiffeq's
+    step control (`_select_initial_step`, the RMS error ratio against atol + rtol max(|y0|, |y1|), safety 0.9, growth at most
+    10) is Hairer's, and scipy's RK45 -- in this image -- implements the same rules for the same Dormand-Prince pair
+    (torchdiffeq's rk_common.py cites scipy for the initial step).  They differ in four places: the error WEIGHTS
+    (torchdiffeq's `c_error` is built from another fourth-order companion -- exactly 2/3 of the published b - b^ that scipy
+    holds, asserted below; the tableau test pins them by their order conditions), what happens AFTER a rejected step (scipy
+    caps the next growth factor at 1), after an accepted step with an error ratio above 0.9^order (scipy shrinks, torchdiffeq
+    keeps the step) and the end of the span (scipy clips the last step, torchdiffeq interpolates).  So
+    scipy's stepper is given the oracle's error weights, and on a smooth problem in float64 the oracle's first step and
+    every step of its rejection-free prefix must then be scipy's, to rounding; a wrong exponent, norm, safety factor or
+    initial-step rule shows at once."""
+    import numpy as np
+    from scipy.integrate import RK23, RK45
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(6, 6)) * 0.4 - 0.8 * np.eye(6)
+
+    def rhs_np(t, y):
+        return A @ y + np.sin(3.0 * t + y) * 0.5
+
+    if method == "dopri5":
+        Base, c_err, order = RK45, np.array([float(c) for c in O._DP5_C_ERR]), 5
+        assert np.allclose(c_err, -2.0 / 3.0 * RK45.E, rtol=0, atol=1e-15)      # same direction, 2/3 of the published estimate
+    else:       # Bogacki-Shampine 3(2) = scipy's RK23: the error weights are the published ones (up to sign)
+        Base, order = RK23, 3
+        c_err = np.array([float(c) for c in O._ADAPTIVE_TABLEAUX["bosh3"][4]])
+        assert O._ADAPTIVE_TABLEAUX["bosh3"][0] == 3 and np.allclose(np.abs(c_err), np.abs(RK23.E), rtol=0, atol=1e-15)
+
+    class RK45WithOracleWeights(Base):
+        E = c_err
+
+    y0 = rng.normal(size=6)
+    total = 0
+    for rtol, atol in ((1e-6, 1e-8), (1e-4, 1e-6), (1e-8, 1e-10), (1e-3, 1e-3), (1e-10, 1e-12)):
+        sp = RK45WithOracleWeights(rhs_np, 0.0, y0, t_bound=100.0, rtol=rtol, atol=atol)
+        first_h = sp.h_abs
+        sp_steps = []
+        for _ in range(40):
+            sp.step()
+            sp_steps.append((sp.t_old, sp.t - sp.t_old))
+        At = torch.tensor(A)
+        func = lambda t, y: (y[0] @ At.T + torch.sin(3.0 * t + y[0]) * 0.5,)
+        O.odeint_dopri5(func, (torch.tensor(y0)[None, :],), torch.tensor([0.0, 4.0], dtype=torch.float64), rtol=rtol, atol=atol,
+                        method=method)
+        steps = O.last_adaptive_stats["steps"]
+        assert abs(steps[0][1] - first_h) <= 1e-12 * first_h                      # the initial-step rule
+        # accepted steps up to and including the first one after the first rejection (the retry follows the same rule in
+        # both; only the step after it may differ: scipy caps its growth at 1)
+        # ... and torchdiffeq never shrinks the step after an ACCEPTED one (its `dfactor` is 1 below an error ratio of 1),
+        # where scipy applies 0.9 ratio^-1/5 whatever it is: the walk also ends behind an accepted ratio above 0.9^5
+        accepted, seen_reject = [], False
+        for t, dt, ratio, ok in steps:
+            if ok:
+                accepted.append((t, dt))
+                if seen_reject or ratio > 0.9 ** order:
+                    break
+            else:
+                seen_reject = True
+        assert len(accepted) >= 2, (rtol, steps[:6])
+        for n, ((t, dt), (ts, hs)) in enumerate(zip(accepted, sp_steps)):
+            assert abs(t - ts) <= 1e-9 * max(1.0, abs(ts)) and abs(dt - hs) <= 1e-7 * hs, (rtol, n, t, dt, ts, hs)
+        total += len(accepted)
+    assert total >= 12, total
