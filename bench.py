@@ -723,22 +723,28 @@ def main():
     head, _ = sm.sample_ode_from_base(z[:256].contiguous(), method="rk4", options=opts)
     rank_invariant = bool(torch.equal(head, x[:256]))
     sharded = None
+    hung = False
     if multi:
         rank_invariant &= bool(torch.equal(gathered[rank * B: rank * B + 256].to(device), x[:256]))
-        if args.extras:
-            try:
-                sharded, ok = sharded_extras(device, world, rank, dist, args.backend, args.c4_rows, args.c5_rows,
-                                             args.c4_steps, args.c5_steps, args.c3_rows, args.c3_steps)
-                rank_invariant &= ok
-            except Exception as exc:      # the headline measurement above must still be reported (ONE line, rank 0)
-                sharded = [{"workload": "sharded BASELINE configs[3] / configs[4] (extras of the N > 1 run)", "error": repr(exc)}]
-                rank_invariant = False
         flag = torch.tensor([1.0 if rank_invariant else 0.0], device=gather_dev, dtype=torch.float64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # the headline's invariance, over all ranks
         rank_invariant = bool(flag.item() == 1.0)
-        # last of all, guarded: the adaptive path's exchange step has never run under RCCL before a node runs this line
-        hung = False
-        if args.extras and args.adaptive_rows > 0:
+        # Everything below is extra and runs behind a watchdog thread: the multi-rank collectives of these sections have
+        # never run under RCCL before a node runs this line, and one that never completes must not take the measured
+        # headline with it.  After a hang this rank issues no further collective, prints (rank 0) and leaves.
+        if args.extras:
+            res, why = run_guarded(lambda: sharded_extras(device, world, rank, dist, args.backend, args.c4_rows, args.c5_rows,
+                                                          args.c4_steps, args.c5_steps, args.c3_rows, args.c3_steps),
+                                   900, device)
+            if res is not None:
+                sharded, ok = res
+                rank_invariant &= ok                                   # (already MIN-reduced over the ranks inside)
+            else:
+                hung = why.startswith("no answer")
+                sharded = [{"workload": "sharded BASELINE configs[2] / [3] / [4] (extras of the N > 1 run)", "error": why}]
+                rank_invariant = False
+        # last of all: the adaptive path's exchange step
+        if args.extras and args.adaptive_rows > 0 and not hung:
             res, why = run_guarded(lambda: adaptive_exchange_extra(device, world, rank, dist, args.backend, args.adaptive_rows),
                                    300, device)
             hung = res is None and why is not None and why.startswith("no answer")
@@ -868,7 +874,8 @@ def main():
             out["streaming_helpers"] = streaming_helpers(device)
         print(json.dumps(out), flush=True)
     if multi:
-        if hung:                 # a rank stuck in a collective cannot tear the group down: the line is out, leave
+        if hung or any("error" in e for e in (sharded or [])):
+            # a rank stuck in a collective (or whose peers may be) cannot tear the group down: the line is out, leave
             sys.stdout.flush()
             os._exit(0)
         dist.destroy_process_group()
