@@ -613,6 +613,10 @@ def main():
                     help="collective backend for N > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
                     help="skip the one-launch timings of BASELINE configs 3, 4, 5 (N = 1 only)")
+    ap.add_argument("--watchdog-seconds", type=float, nargs=2, default=(900.0, 300.0),
+                    help="N > 1: patience with the sharded extras / the adaptive extra before the line is printed without them")
+    ap.add_argument("--test-desert-rank", type=int, default=-1,
+                    help="tests: this rank stays away from the adaptive extra, so the others wait for it in a collective")
     ap.add_argument("--group-of-one", action="store_true",
                     help="rehearsal: run the N > 1 branch with a one-rank process group (needs --gpus 1)")
     ap.add_argument("--single-device", action="store_true",
@@ -735,7 +739,7 @@ def main():
         if args.extras:
             res, why = run_guarded(lambda: sharded_extras(device, world, rank, dist, args.backend, args.c4_rows, args.c5_rows,
                                                           args.c4_steps, args.c5_steps, args.c3_rows, args.c3_steps),
-                                   900, device)
+                                   args.watchdog_seconds[0], device)
             if res is not None:
                 sharded, ok = res
                 rank_invariant &= ok                                   # (already MIN-reduced over the ranks inside)
@@ -745,8 +749,12 @@ def main():
                 rank_invariant = False
         # last of all: the adaptive path's exchange step
         if args.extras and args.adaptive_rows > 0 and not hung:
-            res, why = run_guarded(lambda: adaptive_exchange_extra(device, world, rank, dist, args.backend, args.adaptive_rows),
-                                   300, device)
+            if rank == args.test_desert_rank:
+                time.sleep(args.watchdog_seconds[1] + 6.0)            # alive but absent: the others' collective cannot finish
+                res, why = None, "deserted (test)"
+            else:
+                res, why = run_guarded(lambda: adaptive_exchange_extra(device, world, rank, dist, args.backend,
+                                                                       args.adaptive_rows), args.watchdog_seconds[1], device)
             hung = res is None and why is not None and why.startswith("no answer")
             entry = res if res is not None else {"workload": "default-argument log_prob sharded with whole-batch step control",
                                                  "error": why}

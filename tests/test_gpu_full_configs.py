@@ -454,3 +454,32 @@ def test_bench_multi_rank_branch_under_rccl_with_one_rank():
     extras = rec["extra_configs"]
     assert len(extras) == 4 and all("error" not in e for e in extras), extras
     assert all(e["rank_invariant"] for e in extras[:3]) and extras[3]["steps_equal_whole_batch_solve_on_all_ranks"] is True
+
+
+def test_bench_line_survives_a_collective_that_never_completes():
+    """The N > 1 extras run behind a watchdog: here rank 1 stays away from the last one, rank 0 waits for it in a collective
+    for ever -- after the watchdog's patience (8 s in this test) rank 0 must still print the ONE line, with the headline
+    intact and an `error` entry in place of the extra, and every process must end with exit code 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--steps", "1", "--warmup", "0", "--cpu-batch", "0", "--batch", "8192", "--c3-rows", "2100", "--c3-steps", "4",
+           "--c4-rows", "2100", "--c4-steps", "4", "--c5-rows", "2100", "--c5-steps", "8", "--adaptive-rows", "2001",
+           "--watchdog-seconds", "600", "8", "--test-desert-rank", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["rank_invariant"] is True
+    extras = rec["extra_configs"]
+    assert len(extras) == 4 and all("error" not in e for e in extras[:3])
+    assert "no answer within" in extras[3]["error"]
