@@ -483,3 +483,30 @@ def test_bench_line_survives_a_collective_that_never_completes():
     extras = rec["extra_configs"]
     assert len(extras) == 4 and all("error" not in e for e in extras[:3])
     assert "no answer within" in extras[3]["error"]
+
+
+def test_offsets_beyond_two_gib():
+    """2^25 x 16 fp32 = 2 GiB per array: element offsets cross 2^31 bytes in the fused kernel, the counter-based fill and the
+    streaming helpers.  Slices of the huge batch solved on their own return its rows bit for bit (first, middle, last)."""
+    from flowfusion_amd import _native
+    from flowfusion_amd.diffusion import MLP, VPSDE, ScoreModel
+    torch.manual_seed(5)
+    sm = ScoreModel(MLP(16, 0, 8, [256] * 4), VPSDE(), no_sigma=True).eval().to(DEV)
+    eps = float(sm.sde.epsilon)
+    B = 1 << 25
+    z = _native.normal_fill(B, 16, 7, 0, DEV)
+    assert torch.equal(_native.normal_fill(100, 16, 7, B - 100, DEV), z[B - 100:])
+    o = {"step_size": (1.0 - eps) / 2}
+    x, _ = sm.sample_ode_from_base(z, method="euler", options=o)
+    for lo in (0, B // 2 - 5, B // 2 + 12345, B - 1000):
+        part, _ = sm.sample_ode_from_base(z[lo:lo + 1000].contiguous(), method="euler", options=o)
+        assert torch.equal(part, x[lo:lo + 1000]), lo
+    got = _native.scaled_rms([(x, None, z, x)], 1e-3, 1e-3, check=x)
+    tail = slice(B - (1 << 20), B)
+    ref_tail = ((x[tail].double() / (1e-3 + 1e-3 * torch.max(z[tail].abs(), x[tail].abs()).double())) ** 2).sum()
+    ref_head = ((x[: B - (1 << 20)].double() / (1e-3 + 1e-3 * torch.max(z[: B - (1 << 20)].abs(), x[: B - (1 << 20)].abs()).double())) ** 2).sum()
+    ref = float(((ref_tail + ref_head) / x.numel()).sqrt())
+    assert abs(got[0] - ref) < 1e-5 * ref and got[1] == 0.0
+    keep = (x[-1000:] + 0.5 * z[-1000:]).clone()
+    _native.stage_combine(z, x, [z], [0.5], 1.0)                         # in place over 2 GiB: z <- x + 0.5 z
+    assert torch.equal(z[-1000:], keep)
