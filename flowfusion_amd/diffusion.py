@@ -30,7 +30,7 @@ from torch.distributions import Normal
 from . import adaptive, device_adaptive, generic, solvers
 from . import _native
 from . import host_stepper, trace_estimators
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, require_fp32, within_envelope
 
 
 # ------------------------------------------------------------------------------------------------
@@ -380,6 +380,7 @@ class ScoreModel(nn.Module):
         fixed-grid methods as one launch, the adaptive methods with the step control on the device.  ``affine``
         (in_shift / in_scale / out_scale / out_shift, the PopulationModel wrappers' pre- and post-processing)
         rides in the kernel's prologue / epilogue on fixed grids and is applied around the adaptive loop."""
+        require_fp32(self, x, cond, probe, what="an ODE solve")
         if not self._fusable():
             return self._solve_generic(x, t_span, method, options, mode, atol, rtol, affine)
         net = self._net()
@@ -466,6 +467,7 @@ class ScoreModel(nn.Module):
         standard-normal slab (tests inject the reference's captured stream here); with
         ``rng = (seed, global index of row 0)`` the kernel draws the normals itself.  The steps run in as few
         launches as the noise memory and the progress granularity allow (one, normally)."""
+        require_fp32(self, x, conditional, what="sample_sde")
         if not self._fusable():
             if rng is not None:
                 raise NotImplementedError("noise='philox' lives in the fused kernel; a custom score module samples with noise='torch'")

@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import _native, adaptive, device_adaptive, generic, solvers
-from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, within_envelope
+from .fused import FusedNet, MODE_EXACT, MODE_HUTCH, MODE_STATE, activation_spec, require_fp32, within_envelope
 
 _DEFAULT_SAMPLE_METHOD = "dopri5"     # what odeint() picks when the reference passes no method
 
@@ -119,6 +119,7 @@ class _FlowBase(nn.Module):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
     def _solve(self, x, t_span, method, options, mode, atol, rtol, cond=None, probe=None, raw_cond=None, **affine):
+        require_fp32(self, x, cond, probe, what="an ODE solve")
         if not self._fusable():
             return self._solve_generic(x, t_span, method, options, mode, atol, rtol, cond, probe, raw_cond, affine)
         net = self._net()

@@ -290,3 +290,17 @@ class FusedNet:
                 f"precision={self.precision!r} with {self.dim} state dimensions keeps {self.stage_slots(mode)} Runge-Kutta stage "
                 f"slots on chip and {what} needs {used}: use euler / midpoint / heun3 / rk4 / rk4_classic (or bosh3 / fehlberg2 "
                 "/ adaptive_heun), or precision='f32'")
+
+
+def require_fp32(module, *tensors, what="this solve"):
+    """The kernels compute in fp32, the dtype the reference's constructors create (and every BASELINE configuration uses).
+    The reference itself follows the dtype of its parameters and inputs -- a ``.double()`` model solves in float64 there --
+    so anything else is refused here rather than rounded to fp32 behind the caller's back."""
+    for p in module.parameters():
+        if p.dtype != torch.float32:
+            raise TypeError(f"flowfusion_amd: {what} computes in float32; the model holds {p.dtype} parameters (the reference "
+                            "would solve in that dtype) -- cast the model with .float()")
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and t.is_floating_point() and t.dtype != torch.float32:
+            raise TypeError(f"flowfusion_amd: {what} computes in float32; got a {t.dtype} input (the reference would "
+                            "solve in that dtype) -- cast it with .float()")

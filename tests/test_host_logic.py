@@ -653,3 +653,19 @@ def test_replaced_layer_invalidates_the_fused_view(built_library):
     nf = f._net()
     f.layers[2] = torch.nn.Linear(64, 64)
     assert f._net() is not nf
+
+
+def test_other_dtypes_are_refused_not_rounded(built_library):
+    """The reference follows the dtype of its parameters and inputs (a `.double()` model solves in float64 there); the
+    kernels compute in fp32 only, so a float64 model or input is refused with a TypeError instead of being rounded."""
+    from flowfusion_amd import flow as Fm
+    sm = D.ScoreModel(D.MLP(4, 0, 8, [64]), D.VPSDE()).eval()
+    with pytest.raises(TypeError, match="float32"):
+        sm.sample_ode_from_base(torch.randn(8, 4, dtype=torch.float64), method="rk4", options={"step_size": 0.1})
+    with pytest.raises(TypeError, match="float32"):
+        sm.double().log_prob(torch.randn(8, 4), method="rk4", options={"step_size": 0.1})
+    with pytest.raises(TypeError, match="float32"):
+        sm.sample_sde((8, 4), steps=3)
+    f = Fm.ODEFlow(3, [64, 64]).eval().double()
+    with pytest.raises(TypeError, match="float32"):
+        f.sample(torch.randn(4, 3))
