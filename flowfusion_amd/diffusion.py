@@ -749,6 +749,9 @@ class PopulationModelDiffusion(nn.Module):
         self.options = options
 
     def forward(self, base_samples):
+        if self.scale.dtype != torch.float32 or self.shift.dtype != torch.float32:
+            # (e.g. float64 statistics from numpy: the reference's `* scale + shift` then promotes the result -- so does this)
+            return self.score_model._sample_ode(base_samples, None, 1e-5, 1e-5, self.method, self.options) * self.scale + self.shift
         return self.score_model._sample_ode(base_samples, None, 1e-5, 1e-5, self.method, self.options,
                                             out_scale=self.scale, out_shift=self.shift)
 
@@ -784,6 +787,9 @@ class PopulationModelDiffusionConditional(nn.Module):
         return (conditional - self.conditional_shift) / self.conditional_scale
 
     def forward(self, base_samples, conditional=None):
+        if self.scale.dtype != torch.float32 or self.shift.dtype != torch.float32:
+            return self.score_model._sample_ode(base_samples, self._cond(conditional), 1e-5, 1e-5, self.method,
+                                                self.options) * self.scale + self.shift
         return self.score_model._sample_ode(base_samples, self._cond(conditional), 1e-5, 1e-5, self.method,
                                             self.options, out_scale=self.scale, out_shift=self.shift)
 

@@ -283,6 +283,26 @@ def test_population_wrapper_hutchinson_log_prob_fixed_seed():
     assert _logp_err(lp, po32.log_prob(x, None, 1e-5, 1e-5, "hutch", e)) < ADAPT_TOL
 
 
+def test_population_wrapper_with_float64_statistics():
+    """shift / scale computed with numpy arrive as float64 buffers: the reference's `solve * scale + shift` then promotes the
+    samples to float64 (diffusion.py:1575-1585), and so does the wrapper here (the affine leaves the kernel's epilogue for
+    that case); the float32 solve underneath is the same.  A float64 input to the network is refused (the reference's
+    Linear layers raise on it as well)."""
+    from flowfusion_amd.diffusion import MLP, VESDE, PopulationModelDiffusion
+    torch.manual_seed(3)
+    net = MLP(5, 0, 8, [128, 128])
+    shift, scale = torch.randn(5), torch.rand(5) + 0.5
+    opts = {"step_size": 0.05}
+    p32 = PopulationModelDiffusion(net, VESDE(), shift=shift, scale=scale, method="rk4", options=opts).eval().to(DEV)
+    p64 = PopulationModelDiffusion(net, VESDE(), shift=shift.double(), scale=scale.double(), method="rk4", options=opts).eval().to(DEV)
+    z = torch.randn(300, 5, device=DEV)
+    a, b = p32(z), p64(z)
+    assert a.dtype == torch.float32 and b.dtype == torch.float64
+    assert (a.double() - b).abs().max().item() < 1e-5 * b.abs().max().item()
+    with pytest.raises(TypeError, match="float32"):
+        p64.log_prob(b)
+
+
 def test_replaced_layer_is_repacked():
     """a layer swapped after the first solve must not keep integrating with the old weights."""
     sm, _, _ = _seeded_score_model(16, 0, [64, 64, 64], "VPSDE", True, 181)
