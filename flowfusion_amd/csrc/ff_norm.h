@@ -72,6 +72,24 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
     // the array a second time (12 instead of 16 bytes per element, one pass instead of two).
     const bool fold_check = a.n_terms > 0 && a.check != nullptr && a.check == a.s1[0] && a.n_check == a.n[0];
     double bad = 0.0;
+    // a grand total becomes a result (thread 0; t == n_terms: the non-finite count)
+    auto publish = [&](int t, double tot) __attribute__((always_inline)) {
+        const int col = t < a.n_terms ? t : FF_NORM_TERMS;
+        if (a.sums) {
+            a.sums[col] = tot;
+            if (t < a.n_terms) a.sums[FF_NORM_TERMS + 1 + t] = (double)a.n[t];
+        } else if (t < a.n_terms) {
+            res[t] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
+            if (a.out) a.out[t] = res[t];
+        } else {
+            res[FF_NORM_TERMS] = tot > 0.0 ? 1.f : 0.f;
+            if (a.out) a.out[a.n_terms] = res[FF_NORM_TERMS];
+        }
+    };
+    // One block (small states: the notebook-scale solves): its totals ARE the grand totals -- no partials, no arrival
+    // counter, four dependent trips to memory less per launch.  The same numbers: the partial path would add this block's
+    // total to zeros.
+    const bool solo = gridDim.x == 1;
     for (int t = 0; t < a.n_terms; ++t) {
         double acc = 0.0;
         const float* num = a.num[t]; const float* sub = a.sub[t]; const float* s0 = a.s0[t]; const float* s1 = a.s1[t];
@@ -104,7 +122,10 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
             if (chk) bad += (s1[i] - s1[i] == 0.f) ? 0.0 : 1.0;
         }
         const double tot = block_sum(acc, sh);
-        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
+        if (threadIdx.x == 0) {
+            if (solo) publish(t, tot);
+            else a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + t] = tot;
+        }
     }
     {
         if (!fold_check) {
@@ -120,7 +141,19 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
             }
         }
         const double tot = block_sum(bad, sh);
-        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
+        if (threadIdx.x == 0) {
+            if (solo) publish(a.n_terms, tot);
+            else a.partial[(size_t)blockIdx.x * (FF_NORM_TERMS + 1) + FF_NORM_TERMS] = tot;
+        }
+    }
+    if (solo) {
+        if (threadIdx.x == 0) {
+            last = true;
+            if (a.sums)
+                for (int t = a.n_terms; t < FF_NORM_TERMS; ++t) { a.sums[t] = 0.0; a.sums[FF_NORM_TERMS + 1 + t] = 0.0; }
+        }
+        __syncthreads();
+        return true;
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -137,18 +170,7 @@ __device__ __forceinline__ bool scaled_rms_reduce(const NormArgs& a, double* sh,
             for (unsigned b = threadIdx.x; b < gridDim.x; b += blockDim.x)
                 acc += __builtin_nontemporal_load(&a.partial[(size_t)b * (FF_NORM_TERMS + 1) + col]);
             const double tot = block_sum(acc, sh);
-            if (threadIdx.x == 0 && a.sums) {
-                a.sums[col] = tot;
-                if (t < a.n_terms) a.sums[FF_NORM_TERMS + 1 + t] = (double)a.n[t];
-            } else if (threadIdx.x == 0) {
-                if (t < a.n_terms) {
-                    res[t] = a.n[t] > 0 ? (float)sqrt(tot / (double)a.n[t]) : 0.f;
-                    if (a.out) a.out[t] = res[t];
-                } else {
-                    res[FF_NORM_TERMS] = tot > 0.0 ? 1.f : 0.f;
-                    if (a.out) a.out[a.n_terms] = res[FF_NORM_TERMS];
-                }
-            }
+            if (threadIdx.x == 0) publish(t, tot);
         }
         if (threadIdx.x == 0 && a.sums)
             for (int t = a.n_terms; t < FF_NORM_TERMS; ++t) { a.sums[t] = 0.0; a.sums[FF_NORM_TERMS + 1 + t] = 0.0; }
@@ -177,6 +199,7 @@ inline unsigned norm_args_from_terms(NormArgs& k, const ff_norm_term* terms, int
     k.counter = (unsigned*)workspace;
     k.partial = (double*)((char*)workspace + 16);
     k.sums = nullptr;
+    if (most / 4 <= 2048) return 1;                       // up to eight trips of one block: the single-block path (no arrival counter)
     long long want = (most / 4 + 255) / 256;              // one 16-byte access per thread and trip
     return (unsigned)(want < 1 ? 1 : (want > kNormBlocks ? kNormBlocks : want));
 }
