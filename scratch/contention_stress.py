@@ -94,6 +94,16 @@ for units in ([128], [256], [64, 64, 64], [256] * 3, [128] * 5):          # odd 
     tag = "x".join(str(u) for u in units)
     stress(f"4d ve {tag} adaptive sample B=800", lambda: g.sample_ode_from_base(z)[0], reps=REPS // 2)
     stress(f"4d ve {tag} rk4 exact log_prob B=800", lambda: g.log_prob(z * 0.1, method="rk4", options={"step_size": 0.05}), reps=REPS // 2)
+# the other tile shapes' twins: 32-column kernels (width 128 beyond 16 dimensions), width 256 up to 64 dimensions
+for Dx, units in ((20, [128] * 3), (40, [256] * 3), (24, [128]), (33, [256, 256])):
+    torch.manual_seed(9)
+    g = ScoreModel(MLP(Dx, 0, 8, units), VESDE()).eval().to(dev)
+    z = torch.randn(700, Dx, device=dev) * 3
+    tag = f"{Dx}d ve " + "x".join(str(u) for u in units)
+    stress(f"{tag} adaptive sample B=700", lambda: g.sample_ode_from_base(z)[0], reps=REPS // 2)
+    stress(f"{tag} rk4 sample B=700", lambda: g.sample_ode_from_base(z, method="rk4", options={"step_size": 0.1})[0], reps=REPS // 2)
+    g.hutch = True
+    stress(f"{tag} adaptive hutch log_prob B=700", lambda: g.log_prob(z * 0.1, probe="philox", seed=2), reps=REPS // 2)
 # the estimators' Jacobian output (jac_out / jac_all: written by wavefront 0 of a cooperative workgroup)
 for kw in ({"hutchpp": True, "hpp_rank": 2, "hpp_vecs": 2}, {"xtrace": True, "xt_vecs": 3}):
     torch.manual_seed(7)
