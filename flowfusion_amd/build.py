@@ -227,12 +227,12 @@ def _gen_sources() -> list[Path]:
     )
     rows = ",\n".join(
         f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, {i[7]}, launch_{_inst_name(*i)}, "{_inst_name(*i)}", '
-        + (f"launch_{_inst_name(*i)}_coop" if _has_coop(i[1], i[7]) else "nullptr") + "}"
+        + (f"launch_{_inst_name(*i)}_coop" if _has_coop(i[1], i[7]) else "nullptr") + f", {i[5]}}}"
         for i in INSTANCES
     )
     # wide catch-alls: no one-wavefront kernel (launch = nullptr), the cooperative launcher serves every batch size
     rows += ",\n" + ",\n".join(
-        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, 0, nullptr, "{_wide_name(*i)}", launch_{_wide_name(*i)}}}'
+        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, 0, nullptr, "{_wide_name(*i)}", launch_{_wide_name(*i)}, 0}}'
         for i in WIDE_INSTANCES
     )
     table = f"""// generated by flowfusion_amd/build.py -- do not edit

@@ -479,18 +479,65 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     // in about a third of the time.  Same packed weights, bitwise the same results.  FF_COOP=0 / 1 pins the choice.
     const long long spt = plan->tile / (1 + nt);           // samples per tile
     const long long tiles = (a->batch + spt - 1) / spt;
-    // (two workgroups of a <= 256-wide twin share a CU: it still wins at three quarters of a chip's worth of tiles)
-    bool coop = k.launch_coop != nullptr && tiles <= (plan->width <= 256 ? 768 : 512);
+    // One rule for whole launches and for tails (below): `n` tiles on the one-wavefront kernel run with ceil(n / 1024)
+    // wavefronts per SIMD and take that many wps-ths of a full round; on the twin they take n / (0.8 chip) of a round, never
+    // less than 0.3 (measured, scratch/tail_split.py and scratch/coop_threshold.py).  The twin serves whatever it is faster at.
+    const long long chip = 1024ll * (k.wps > 0 ? k.wps : 1);
+    auto twin_wins = [&](long long n) {
+        const double one_wave = (double)((n + 1023) / 1024) / (double)(k.wps > 0 ? k.wps : 1);
+        const double twin = n / (0.8 * (double)chip) > 0.30 ? n / (0.8 * (double)chip) : 0.30;
+        return twin < one_wave;
+    };
+    bool coop = k.launch_coop != nullptr && tiles <= chip && twin_wins(tiles);
     if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
     const bool wide = k.launch == nullptr;                 // wide catch-all: cooperative at every batch size, one exchange buffer
     if (wide) coop = true;
-    const long long grid = coop ? tiles : (tiles + 3) / 4;
-    if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
+    // The tail of a launch.  The chip runs 1024 * wps tiles at once; the tiles left over after the full rounds run as a last
+    // round with w = ceil(leftover / 1024) wavefronts per SIMD, which takes w / wps of a full round's time (measured: the
+    // dispatcher fills SIMDs evenly, a wavefront does not finish sooner for having fewer neighbours than wps allows).
+    // The cooperative twin -- a tile per workgroup, bitwise the same results -- gets through about 0.8-0.9 of a chip's worth
+    // of tiles in a round's time and never needs less than ~0.3 of it.  Whenever that is the shorter of the two, the
+    // leftover rows go to the twin as a second launch (scratch/tail_split.py: up to +34 % just above a whole number of
+    // rounds, +5 % at eight rounds).  FF_TAIL_SPLIT=0 switches it off (A/B runs, tests).
+    long long tail_tiles = 0;
+    if (!coop && k.launch_coop != nullptr && k.wps > 0 && !a->jac_out) {
+        const long long rem = tiles % chip;
+        const char* pin = getenv("FF_TAIL_SPLIT");
+        if (tiles > chip && rem > 0 && !(pin && atoi(pin) == 0)) {
+            bool split = twin_wins(rem);
+            if (const char* m = getenv("FF_TAIL_MAX")) split = rem <= atoll(m);          // (experiments: scratch/tail_split.py)
+            if (split) tail_tiles = rem;
+        }
+    }
     const unsigned slots = ff::kSlots * (plan->dregs / 4) * 64 * 16;
     const unsigned kh = (plan->width / 32) * ff::tile_rb(plan->tile);                 // operand registers of a hidden layer
-    const unsigned lds = coop ? slots + (wide ? 1u : 2u) * (kh / 4) * 64 * 16 : 4u * slots;
-    if (lds > 160u * 1024u) return FF_ERR_UNSUPPORTED;
-    const int herr = (coop ? k.launch_coop : k.launch)(&ka, (unsigned)grid, lds, (hipStream_t)hip_stream);
+    const unsigned lds_coop = slots + (wide ? 1u : 2u) * (kh / 4) * 64 * 16, lds_wave = 4u * slots;
+    if ((coop || tail_tiles ? lds_coop : 0u) > 160u * 1024u || (!coop ? lds_wave : 0u) > 160u * 1024u) return FF_ERR_UNSUPPORTED;
+    const long long main_tiles = tiles - tail_tiles;
+    const long long grid = coop ? main_tiles : (main_tiles + 3) / 4;
+    if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
+    if (tail_tiles) ka.batch = main_tiles * spt;                                       // (full tiles only: < a->batch)
+    int herr = (coop ? k.launch_coop : k.launch)(&ka, (unsigned)grid, coop ? lds_coop : lds_wave, (hipStream_t)hip_stream);
+    if (herr == 0 && tail_tiles) {
+        // the same launch over rows [row0, batch): every per-row array moves on by row0 rows, the counter-based noise by row0 samples
+        const long long row0 = main_tiles * spt, D = plan->dim, C = plan->cond_dim;
+        ff::KernelArgs t = ka;
+        t.batch = a->batch - row0;
+        t.x_in += row0 * D; t.x_out += row0 * D;
+        if (t.cond) t.cond += row0 * C;
+        if (t.probe) t.probe += row0 * D;
+        if (t.dlogp_out) t.dlogp_out += row0;
+        if (t.dlogp_in) t.dlogp_in += row0;
+        if (t.noise) t.noise += row0 * D;
+        if (t.k1_in) t.k1_in += row0 * D;
+        if (t.kl1_in) t.kl1_in += row0;
+        for (int j = 0; j < FF_MAX_AUX; ++j) {
+            if (t.aux_out[j]) t.aux_out[j] += row0 * D;
+            if (t.aux_lp_out[j]) t.aux_lp_out[j] += row0;
+        }
+        t.rng_sample_offset += row0;
+        herr = k.launch_coop(&t, (unsigned)tail_tiles, lds_coop, (hipStream_t)hip_stream);
+    }
     if (herr != 0) { t_last_hip_error = herr; return FF_ERR_HIP; }
     return FF_OK;
 }

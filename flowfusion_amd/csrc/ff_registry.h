@@ -20,6 +20,7 @@ struct KernelEntry {
     LaunchFn launch;
     const char* name;
     LaunchFn launch_coop;   // cooperative twin for small batches (one tile per workgroup, ff_mlp_ode.hpp COOP) or NULL
+    int wps;        // wavefronts per SIMD the one-wavefront kernel is built for (its launch bound): 1024 * wps tiles run at once
 };
 
 // defined in the generated ff_table.cpp

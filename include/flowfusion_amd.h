@@ -252,6 +252,9 @@ int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* 
  *   odeint(self.dynamics, (xT[, cond]), t)                 flow.py:299-303, 792-796            FF_MODE_STATE
  *   odeint(self.dynamics_with_jacobian, (x[, cond], logJ)) flow.py:371-382, 869-881            FF_MODE_EXACT
  * Returns FF_OK once enqueued; on any error nothing is enqueued.
+ * One call may enqueue TWO kernels: the rows left over after the full rounds of tiles the chip runs at once go to the
+ * small-batch twin of the kernel when that is faster (same arithmetic, bitwise the same results; FF_TAIL_SPLIT=0 in the
+ * environment keeps one kernel).  Batches below one round run on the twin alone where it wins (FF_COOP=0/1 pins that).
  */
 int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* args, void* hip_stream);
 

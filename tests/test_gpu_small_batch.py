@@ -160,3 +160,54 @@ def test_wide_catch_all_kernels_against_oracle(D, C, units, sde):
     it = iter(noise)
     s = sm._sample_sde_from(base.to(DEV), lambda like: next(it).to(DEV), cd, steps=5)
     assert _state_err(s, so32.sample_sde(base, list(noise), cond, steps=5)) < STATE_TOL
+
+
+def test_tail_of_a_launch_goes_to_the_twin(monkeypatch):
+    """A launch of a few rounds whose leftover tiles are few: the leftover rows run on the cooperative twin as a second
+    launch (ff_mlp_ode_launch, "the tail of a launch").  Every mode, with FF_TAIL_SPLIT=0 as the unsplit yardstick: bitwise
+    the same outputs -- state, divergence, in-kernel and supplied noise, the adaptive attempt's auxiliary outputs (through
+    a default-argument solve), conditional inputs."""
+    from flowfusion_amd.diffusion import MLP, VESDE, VPSDE, ScoreModel
+    torch.manual_seed(0)
+    sm = ScoreModel(MLP(16, 0, 8, [256] * 4), VPSDE(), no_sigma=True).eval().to(DEV)       # 2 wavefronts per SIMD: 2048 tiles at once
+    nb = ScoreModel(MLP(2, 0, 8, [128] * 3), VESDE()).eval().to(DEV)                       # 3 per SIMD: 3072
+    cm = ScoreModel(MLP(8, 3, 8, [256] * 2), VESDE()).eval().to(DEV)
+    eps = float(sm.sde.epsilon)
+    o = {"step_size": (1.0 - eps) / 3}
+
+    def both(fn):
+        monkeypatch.setenv("FF_TAIL_SPLIT", "0")
+        a = fn()
+        monkeypatch.delenv("FF_TAIL_SPLIT")
+        return a, fn()
+
+    z = torch.randn(2048 * 16 + 500, 16, device=DEV)                                        # state: 16 samples per tile
+    a, b = both(lambda: sm.sample_ode_from_base(z, method="rk4", options=o)[0])
+    assert torch.equal(a, b)
+    sm.hutch = True
+    x = torch.randn(2048 * 8 * 2 + 77, 16, device=DEV) * 0.5                                # Hutchinson: 8 per tile, two rounds + 10 tiles
+    a, b = both(lambda: sm.log_prob(x, method="rk4", options=o, probe="philox", seed=3))
+    assert torch.equal(a, b)
+    sm.hutch = False
+    p = torch.randn(3072 * 5 + 301, 2, device=DEV) * 0.3                                    # exact trace, 2-d: 5 samples per tile
+    a, b = both(lambda: nb.log_prob(p, method="rk4", options={"step_size": 0.25}))
+    assert torch.equal(a, b)
+    pr = torch.randn(2048 * 16 + 999, 16, device=DEV)
+    a, b = both(lambda: sm._sample_sde_from(pr.clone(), None, None, 12, rng=(4, 123456)))   # in-kernel noise keyed by the global row
+    assert torch.equal(a, b)
+
+    def em_torch():
+        torch.manual_seed(5)
+        return sm.sample_sde((2048 * 16 + 40, 16), steps=6)
+    a, b = both(em_torch)                                                                   # supplied noise slabs
+    assert torch.equal(a, b)
+    c = torch.randn(2048 * 16 + 333, 3, device=DEV)
+    zc = torch.randn(2048 * 16 + 333, 8, device=DEV)
+    a, b = both(lambda: cm.sample_ode_from_base(zc, conditional=c, method="midpoint", options={"step_size": 0.2})[0])
+    assert torch.equal(a, b)
+    zn = torch.randn(50000, 2, device=DEV) * 3                                              # the notebook call: 3125 tiles, 53 left over
+    a, b = both(lambda: nb.sample_ode_from_base(zn)[0])                                     # adaptive: k1_in and four auxiliary outputs
+    assert torch.equal(a, b) and nb.last_solver_stats["accepted"] >= 5
+    pn = torch.randn(3072 * 5 + 120, 2, device=DEV) * 0.4
+    a, b = both(lambda: nb.log_prob(pn))                                                    # adaptive with the divergence
+    assert torch.equal(a, b)
