@@ -485,8 +485,11 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     const long long chip = 1024ll * (k.wps > 0 ? k.wps : 1);
     auto twin_wins = [&](long long n) {
         const double one_wave = (double)((n + 1023) / 1024) / (double)(k.wps > 0 ? k.wps : 1);
-        const double twin = n / (0.8 * (double)chip) > 0.30 ? n / (0.8 * (double)chip) : 0.30;
-        return twin < one_wave;
+        // the twin's shortest launch, in rounds of the one-wavefront kernel: 0.31-0.39 at width 512 (one wavefront per SIMD),
+        // 0.30 at width 256 (two), 0.23 at width 128 (three: a round is longer there, the twin's tile is not)
+        const double least = k.wps >= 3 ? 0.22 : (k.wps == 2 ? 0.30 : 0.35);
+        const double twin = n / (0.8 * (double)chip) > least ? n / (0.8 * (double)chip) : least;
+        return twin < 0.9 * one_wave;          // (a margin: near the break-even the tangent modes favour the one-wavefront kernel)
     };
     bool coop = k.launch_coop != nullptr && tiles <= chip && twin_wins(tiles);
     if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
