@@ -9,6 +9,10 @@ attempted steps is enqueued with ONE C call and the host reads 128 bytes of stat
 same arithmetic split (float64 time, fp32 state), same attempt / accept counts as the host controller
 (``tests/test_gpu_device_adaptive.py`` runs both).
 
+Several shards of one batch (one process per GPU): inside ``distributed.global_step_control`` every norm launch is split in
+two and the C driver calls back between them, where the all-reduce of the sums of squares is enqueued
+(``ff_adapt_buffers.exchange``); every rank then walks the same steps, still without a host synchronisation per step.
+
 The host controller stays for what the device one cannot describe: right-hand sides evaluated outside the library
 (``generic.py``, ``host_stepper.py``), SDE classes other than the reference's three, more than 32 embedding frequencies,
 and the CPU kernel-semantics emulator of the tests.  ``FF_HOST_CONTROLLER=1`` forces it (A/B runs).
