@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void adapt_control_kernel(const ControlArgs a)
     // ---- the next launch's evaluation rows ---------------------------------------------------------------------------
     const int S = c.n_stages;
     const int n_rows = kind == adapt::kRowsAttempt ? S - 1 : 1;
-    if (threadIdx.x < n_rows) {
+    if ((int)threadIdx.x < n_rows) {
 #pragma clang fp contract(off)
         const int r = threadIdx.x;
         float ts;
