@@ -251,7 +251,8 @@ int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* 
  *   the Euler-Maruyama loop of sample_sde                  diffusion.py:543-562   FF_MODE_STATE + FF_ROW_NOISE rows
  *   odeint(self.dynamics, (xT[, cond]), t)                 flow.py:299-303, 792-796            FF_MODE_STATE
  *   odeint(self.dynamics_with_jacobian, (x[, cond], logJ)) flow.py:371-382, 869-881            FF_MODE_EXACT
- * Returns FF_OK once enqueued; on any error nothing is enqueued.
+ * Returns FF_OK once enqueued; an argument or shape error enqueues nothing (FF_ERR_HIP from the second of two launches,
+ * below, leaves the first enqueued and the outputs undefined).
  * One call may enqueue TWO kernels: the rows left over after the full rounds of tiles the chip runs at once go to the
  * small-batch twin of the kernel when that is faster (same arithmetic, bitwise the same results; FF_TAIL_SPLIT=0 in the
  * environment keeps one kernel).  Batches below one round run on the twin alone where it wins (FF_COOP=0/1 pins that).
