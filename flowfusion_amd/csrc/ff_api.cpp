@@ -479,17 +479,20 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     // in about a third of the time.  Same packed weights, bitwise the same results.  FF_COOP=0 / 1 pins the choice.
     const long long spt = plan->tile / (1 + nt);           // samples per tile
     const long long tiles = (a->batch + spt - 1) / spt;
-    // One rule for whole launches and for tails (below): `n` tiles on the one-wavefront kernel run with ceil(n / 1024)
-    // wavefronts per SIMD and take that many wps-ths of a full round; on the twin they take n / (0.8 chip) of a round, never
-    // less than 0.3 (measured, scratch/tail_split.py and scratch/coop_threshold.py).  The twin serves whatever it is faster at.
+    // One rule for whole launches and for tails (below), fitted to measurements at widths 128 / 256 / 512 (scratch/tail_split.py,
+    // scratch/tail_margin.py, scratch/coop_threshold.py; in units of a full round of the one-wavefront kernel):
+    //   one-wavefront kernel, n tiles:  ceil(n / 1024) / wps      (n tiles run with that many wavefronts per SIMD; a wavefront
+    //                                                              does not finish sooner for having fewer neighbours)
+    //   twin, n tiles:                  max(least, c0 + n / (0.95 chip)),  chip = 1024 wps tiles in flight,
+    //                                   c0 = 0.10 (0.20 at one wavefront per SIMD), least = 0.22 / 0.30 / 0.35 for wps = 3 / 2 / 1
+    // The twin serves whatever it is faster at.
     const long long chip = 1024ll * (k.wps > 0 ? k.wps : 1);
     auto twin_wins = [&](long long n) {
-        const double one_wave = (double)((n + 1023) / 1024) / (double)(k.wps > 0 ? k.wps : 1);
-        // the twin's shortest launch, in rounds of the one-wavefront kernel: 0.31-0.39 at width 512 (one wavefront per SIMD),
-        // 0.30 at width 256 (two), 0.23 at width 128 (three: a round is longer there, the twin's tile is not)
-        const double least = k.wps >= 3 ? 0.22 : (k.wps == 2 ? 0.30 : 0.35);
-        const double twin = n / (0.8 * (double)chip) > least ? n / (0.8 * (double)chip) : least;
-        return twin < 0.9 * one_wave;          // (a margin: near the break-even the tangent modes favour the one-wavefront kernel)
+        const int wps = k.wps > 0 ? k.wps : 1;
+        const double one_wave = (double)((n + 1023) / 1024) / (double)wps;
+        const double least = wps >= 3 ? 0.22 : (wps == 2 ? 0.30 : 0.35);
+        const double line = (wps == 1 ? 0.20 : 0.10) + n / (0.95 * (double)chip);
+        return (line > least ? line : least) < one_wave;
     };
     bool coop = k.launch_coop != nullptr && tiles <= chip && twin_wins(tiles);
     if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
