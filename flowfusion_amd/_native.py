@@ -129,6 +129,21 @@ class AdaptBuffers(ctypes.Structure):     # ff_adapt_buffers
         ("n_passes", ctypes.c_int32), ("pass_first", ctypes.c_int32 * ADAPT_MAX_PASSES),
         ("pass_count", ctypes.c_int32 * ADAPT_MAX_PASSES),
         ("exchange_sums", ctypes.c_void_p), ("exchange", ctypes.c_void_p), ("exchange_user", ctypes.c_void_p),
+        ("est_kind", ctypes.c_int32), ("est_r", ctypes.c_int32), ("est_m", ctypes.c_int32), ("est_reserved", ctypes.c_int32),
+        ("est_probes0", ctypes.c_void_p), ("est_probes1", ctypes.c_void_p), ("est_jac", ctypes.c_void_p),
+        ("est_div", ctypes.c_void_p), ("est_workspace", ctypes.c_void_p),
+    ]
+
+
+TRACE_HUTCHPP, TRACE_XTRACE = 1, 2        # FF_TRACE_*
+
+
+class TraceArgs(ctypes.Structure):        # ff_trace_args
+    _fields_ = [
+        ("kind", ctypes.c_int32), ("dim", ctypes.c_int32), ("n_rows", ctypes.c_int32), ("r", ctypes.c_int32),
+        ("m", ctypes.c_int32), ("reserved", ctypes.c_int32), ("batch", ctypes.c_int64),
+        ("jac", ctypes.c_void_p), ("probes0", ctypes.c_void_p), ("probes1", ctypes.c_void_p), ("out", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("gate", ctypes.c_void_p),
     ]
 
 
@@ -220,6 +235,12 @@ def lib() -> ctypes.CDLL:
     L.ff_mlp_ode_adaptive.argtypes = [ctypes.POINTER(PlanStruct), ctypes.POINTER(OdeArgs), ctypes.POINTER(AdaptConfig),
                                       ctypes.POINTER(AdaptBuffers), ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                       ctypes.c_int32, ctypes.c_void_p]
+    L.ff_trace_workspace_floats.restype = ctypes.c_size_t
+    L.ff_trace_workspace_floats.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
+    L.ff_trace_estimate.restype = ctypes.c_int
+    L.ff_trace_estimate.argtypes = [ctypes.POINTER(TraceArgs), ctypes.c_void_p]
+    L.ff_trace_estimate_host.restype = ctypes.c_int
+    L.ff_trace_estimate_host.argtypes = [ctypes.POINTER(TraceArgs)]
     L.ff_adapt_host_row.restype = ctypes.c_int
     L.ff_adapt_host_row.argtypes = [ctypes.POINTER(AdaptConfig), ctypes.c_float, ctypes.POINTER(ctypes.c_float),
                                     ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]
@@ -340,6 +361,48 @@ def stage_combine(out: torch.Tensor, x: Optional[torch.Tensor], ks, coefs, x_coe
         rc = lib().ff_stage_combine(ctypes.byref(a), ctypes.c_void_p(stream))
     if rc != FF_OK:
         raise _err(rc, "ff_stage_combine")
+    return out
+
+
+def trace_kind_and_probes(kind: str, probes):
+    """(FF_TRACE_*, probes0, probes1, r, m) from ``kind`` ("hutchpp": probes = (S, G); "xtrace": probes = (O,)), each
+    probe tensor [n, B, D] as the reference stores them (diffusion.py:708-719)."""
+    if kind == "hutchpp":
+        S, G = probes
+        return TRACE_HUTCHPP, S, G, int(S.shape[0]), int(G.shape[0])
+    if kind == "xtrace":
+        (O,) = probes
+        return TRACE_XTRACE, O, None, int(O.shape[0]), 0
+    raise ValueError(f"trace estimator {kind!r}: expected 'hutchpp' or 'xtrace'")
+
+
+def trace_estimate(jac: torch.Tensor, kind: str, probes, host: bool = False) -> torch.Tensor:
+    """ff_trace_estimate: Hutch++ / XTrace divergence estimates [n_rows, B] from recorded Jacobians ``jac``
+    [n_rows, B, D, D] (A = J^T per evaluation row and sample) in ONE launch; ``host=True`` runs the same arithmetic on CPU
+    tensors through ff_trace_estimate_host (tests without a GPU)."""
+    n_rows, B, D, D2 = jac.shape
+    code, p0, p1, r, m = trace_kind_and_probes(kind, probes)
+    if D != D2 or tuple(p0.shape) != (r, B, D) or (p1 is not None and tuple(p1.shape) != (m, B, D)):
+        raise RuntimeError(f"trace_estimate: jac {tuple(jac.shape)} and probes {tuple(p0.shape)} do not match")
+    dev = jac.device
+    if host != (dev.type == "cpu"):
+        raise RuntimeError("flowfusion_amd: ff_trace_estimate works on device memory (host=True: CPU tensors, tests only)")
+    f32 = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+    jac, p0, p1 = f32(jac), f32(p0), f32(p1)
+    out = torch.empty(n_rows, B, dtype=torch.float32, device=dev)
+    items = 1 if host else n_rows * B
+    ws = torch.empty(max(1, int(lib().ff_trace_workspace_floats(code, D, r, items))), dtype=torch.float32, device=dev)
+    a = TraceArgs()
+    a.kind, a.dim, a.n_rows, a.r, a.m, a.batch = code, D, n_rows, r, m, B
+    a.jac, a.probes0, a.probes1 = jac.data_ptr(), p0.data_ptr(), (0 if p1 is None else p1.data_ptr())
+    a.out, a.workspace = out.data_ptr(), ws.data_ptr()
+    if host:
+        rc = lib().ff_trace_estimate_host(ctypes.byref(a))
+    else:
+        with torch.cuda.device(dev):
+            rc = lib().ff_trace_estimate(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != FF_OK:
+        raise _err(rc, "ff_trace_estimate")
     return out
 
 

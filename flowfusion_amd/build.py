@@ -253,6 +253,7 @@ const int g_n_split_kernels = {len(SPLIT_INSTANCES)};
     files.append(CSRC / "ff_api.cpp")
     files.append(CSRC / "ff_aux.hip")
     files.append(CSRC / "ff_adaptive.hip")
+    files.append(CSRC / "ff_trace.hip")
     return files
 
 

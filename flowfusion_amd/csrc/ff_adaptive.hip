@@ -18,6 +18,9 @@
 //   adapt_finish_kernel    torchdiffeq's fourth-order dense output of the last step at t_end (`_interp_fit` /
 //                          `_interp_evaluate`), one pass.
 //   adapt_sum_kernel       FF_MODE_EXACT with more unit tangents than one launch carries: adds the passes' divergences.
+//   adapt_lp_combine_kernel  Hutch++ / XTrace models (ff_adapt_buffers.est_kind; reference flowfusion/diffusion.py:336-481):
+//                          the attempt records every row's Jacobian, ff_trace_estimate (ff_trace.hip) turns them into
+//                          divergence estimates, and this kernel takes the attempt's linear combinations of them.
 //
 // Launches enqueued behind the end of the solve (the host enqueues chunks and reads the state once per chunk) find
 // ff_adapt_state.active == 0 and return at once; so does the fused kernel (ff_ode_args.gate).
@@ -276,6 +279,57 @@ __global__ __launch_bounds__(256) void adapt_sum_kernel(const SumArgs a)
     }
 }
 
+// Divergence slots from ESTIMATES: kl[slot_e] = div[e] for the evaluation rows of the launch (kl[0] = kl1 when the first
+// stage came in), then the same combinations the fused kernel's epilogue takes of its own slots:
+//     out_j = use_y_j * lp0 + sum_s coef_j[s] * kl[s]     coefficients / use_y bits in the two rows behind the evaluation rows
+struct LpCombineArgs {
+    const int* gate;
+    const float* etab;
+    int etab_stride, n_evals, n_aux;
+    const float* div;         // [n_evals][n]
+    const float* kl1;         // [n] or NULL
+    const float* lp0;         // [n] or NULL
+    float* out[FF_MAX_AUX];
+    long long n;
+};
+
+__global__ __launch_bounds__(256) void adapt_lp_combine_kernel(const LpCombineArgs a)
+{
+    if (a.gate && *(const volatile int*)a.gate == 0) return;
+    __shared__ float coef[FF_MAX_AUX][FF_MAX_SLOTS];
+    __shared__ int slot_of[FF_MAX_SLOTS];
+    __shared__ uint32_t use_y;
+    if (threadIdx.x < FF_MAX_AUX * FF_MAX_SLOTS) {
+        const int j = threadIdx.x / FF_MAX_SLOTS, s = threadIdx.x % FF_MAX_SLOTS;
+        const float* row = a.etab + (size_t)(a.n_evals + (j >> 1)) * a.etab_stride;
+        coef[j][s] = row[((j & 1) ? 16 : 8) + s];
+    }
+    if (threadIdx.x < FF_MAX_SLOTS)
+        slot_of[threadIdx.x] = (int)threadIdx.x < a.n_evals ? __builtin_bit_cast(int, a.etab[(size_t)threadIdx.x * a.etab_stride + 4]) : -1;
+    if (threadIdx.x == 0) use_y = __builtin_bit_cast(uint32_t, a.etab[(size_t)a.n_evals * a.etab_stride + 3]);
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        float kl[FF_MAX_SLOTS];
+#pragma unroll
+        for (int s = 0; s < FF_MAX_SLOTS; ++s) kl[s] = 0.f;
+        if (a.kl1) kl[0] = a.kl1[i];
+        for (int e = 0; e < a.n_evals; ++e) {
+            const float d = a.div[(size_t)e * a.n + i];
+#pragma unroll
+            for (int s = 0; s < FF_MAX_SLOTS; ++s) kl[s] = slot_of[e] == s ? d : kl[s];
+        }
+        const float l0 = a.lp0 ? a.lp0[i] : 0.f;
+        for (int j = 0; j < a.n_aux; ++j) {
+            if (!a.out[j]) continue;
+            float part = 0.f;
+#pragma unroll
+            for (int s = 0; s < FF_MAX_SLOTS; ++s) part = __builtin_fmaf(coef[j][s], kl[s], part);
+            a.out[j][i] = (((use_y >> j) & 1u) ? 1.f : 0.f) * l0 + part;
+        }
+    }
+}
+
 static unsigned copy_grid(long long n)
 {
     const long long want = (n / 4 + 255) / 256;
@@ -335,6 +389,10 @@ struct Driver {
             a.dlogp_in = (has_lp && p == 0) ? b->lp : nullptr;
             a.n_aux = n_aux;
             a.jac_out = nullptr; a.jac_all = 0;
+            if (b->est_kind) {                 // the rows' Jacobians leave instead of their traces
+                a.jac_out = b->est_jac; a.jac_all = 1;
+                a.kl1_in = nullptr; a.dlogp_in = nullptr;
+            }
             a.stage_slots = n_evals > 1 ? cfg->n_stages : (with_k1 ? 2 : 1);
             a.gate = gated ? &b->state->active : nullptr;
             a.tangent_first = b->n_passes >= 1 && base->mode == FF_MODE_EXACT ? b->pass_first[p] : 0;
@@ -342,13 +400,29 @@ struct Driver {
             for (int j = 0; j < FF_MAX_AUX; ++j) {
                 a.aux_out[j] = (j < n_aux && p == 0) ? out[j] : nullptr;
                 a.aux_lp_out[j] = nullptr;
-                if (j < n_aux && has_lp)
+                if (j < n_aux && has_lp && !b->est_kind)
                     a.aux_lp_out[j] = P > 1 ? b->aux_lp_pass + ((size_t)p * FF_MAX_AUX + j) * B : out_lp[j];
             }
             const int rc = ff_mlp_ode_launch(plan, &a, stream);
             if (rc != FF_OK) return rc;
         }
-        if (P > 1 && has_lp) {
+        if (b->est_kind) {
+            const int32_t* gate = gated ? &b->state->active : nullptr;
+            ff_trace_args t;
+            memset(&t, 0, sizeof(t));
+            t.kind = b->est_kind; t.dim = (int32_t)D; t.n_rows = n_evals; t.r = b->est_r; t.m = b->est_m; t.batch = B;
+            t.jac = b->est_jac; t.probes0 = b->est_probes0; t.probes1 = b->est_probes1;
+            t.out = b->est_div; t.workspace = b->est_workspace; t.gate = gate;
+            const int rc = ff_trace_estimate(&t, stream);
+            if (rc != FF_OK) return rc;
+            ff::LpCombineArgs c;
+            memset(&c, 0, sizeof(c));
+            c.gate = gate; c.etab = b->etab; c.etab_stride = FF_ROW_HDR + plan->width; c.n_evals = n_evals; c.n_aux = n_aux;
+            c.div = b->est_div; c.kl1 = with_k1 ? b->fl0 : nullptr; c.lp0 = b->lp; c.n = B;
+            for (int j = 0; j < n_aux; ++j) c.out[j] = out_lp[j];
+            hipLaunchKernelGGL(ff::adapt_lp_combine_kernel, dim3(ff::copy_grid(4 * B)), dim3(256), 0, stream, c);
+            if (hipGetLastError() != hipSuccess) return FF_ERR_HIP;
+        } else if (P > 1 && has_lp) {
             ff::SumArgs s;
             memset(&s, 0, sizeof(s));
             s.gate = gated ? &b->state->active : nullptr;
@@ -378,9 +452,14 @@ extern "C" int ff_mlp_ode_adaptive(const ff_mlp_plan_t* plan, const ff_ode_args*
     for (int j = 0; j < FF_MAX_AUX; ++j)
         if (!b->aux[j] || (has_lp && !b->aux_lp[j])) return FF_ERR_BADARG;
     if (has_lp && (!b->lp || !b->fl0 || !b->scratch_lp || !b->out_lp)) return FF_ERR_BADARG;
-    if (b->n_passes < 1 || b->n_passes > FF_ADAPT_MAX_PASSES || (b->n_passes > 1 && (!has_lp || !b->aux_lp_pass))) return FF_ERR_BADARG;
+    if (b->n_passes < 1 || b->n_passes > FF_ADAPT_MAX_PASSES || (b->n_passes > 1 && (!has_lp || (!b->aux_lp_pass && !b->est_kind)))) return FF_ERR_BADARG;
     if (base->batch < 0) return FF_ERR_BADARG;
     if (b->exchange && !b->exchange_sums) return FF_ERR_BADARG;
+    if (b->est_kind) {
+        if (base->mode != FF_MODE_EXACT || (b->est_kind != FF_TRACE_HUTCHPP && b->est_kind != FF_TRACE_XTRACE)) return FF_ERR_BADARG;
+        if (!b->est_probes0 || !b->est_jac || !b->est_div || !b->est_workspace) return FF_ERR_BADARG;
+        if (b->est_r < 1 || b->est_r > plan->dim || (b->est_kind == FF_TRACE_HUTCHPP && (b->est_m < 1 || !b->est_probes1))) return FF_ERR_BADARG;
+    }
     if (base->batch == 0) return b->exchange ? FF_ERR_UNSUPPORTED : FF_OK;     // an empty shard cannot take part in the exchange
 
     Driver d{plan, base, cfg, b, (hipStream_t)hip_stream, (long long)base->batch, (long long)plan->dim, has_lp};

@@ -117,9 +117,21 @@ def _carve(total: torch.Tensor, sizes: Sequence[int]):
     return out
 
 
+def estimator_bytes(net, method: str, B: int, kind: str, probes) -> int:
+    """Device memory an estimator solve adds to the exact-trace one: the Jacobians of every evaluation row of an attempt,
+    their estimates and the factorisation workspace."""
+    code, p0, _, r, _ = _native.trace_kind_and_probes(kind, probes)
+    rows = adaptive.TABLEAUX[method].stages - 1
+    D = net.dim
+    return 4 * (rows * B * D * D + rows * B + int(_native.lib().ff_trace_workspace_floats(code, D, r, rows * B)))
+
+
 def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: float, t_end: float, rtol: float,
-          atol: float, options: Optional[dict], method: str, cond=None, probe=None, norm_only=()):
+          atol: float, options: Optional[dict], method: str, cond=None, probe=None, norm_only=(), estimator=None):
     """``odeint(func, state, [t0, t_end], method=, rtol=, atol=, options=)`` with the loop on the device.
+    ``estimator = (kind, probes)`` (``"hutchpp"``: probes (S, G); ``"xtrace"``: (O,); MODE_EXACT only): the divergence that
+    is integrated is the Hutch++ / XTrace estimate of the reference (diffusion.py:336-481) instead of the exact trace --
+    every attempt records the Jacobians of its evaluation rows, one launch estimates them all, one combines them.
     Returns (y [B, D], lp [B] or None, {"attempts", "accepted", "chunks"})."""
     if not x.is_cuda:
         raise RuntimeError("flowfusion_amd integrates on the GPU only: move the model and its inputs to 'cuda' "
@@ -179,6 +191,24 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
         raise NotImplementedError("more than two norm-only state components")
     for j, c in enumerate(extras):
         b.norm_only[j], b.norm_only_n[j] = c.data_ptr(), c.numel()
+    if estimator is not None:
+        if mode != MODE_EXACT:
+            raise ValueError("a trace estimator replaces the exact trace: mode must be MODE_EXACT")
+        kind, probes = estimator
+        code, p0, p1, r, m = _native.trace_kind_and_probes(kind, probes)
+        if tuple(p0.shape) != (r, B, D) or (p1 is not None and tuple(p1.shape) != (m, B, D)) or r > D:
+            raise RuntimeError(f"{kind} probes of shape {tuple(p0.shape)} do not fit a [{B}, {D}] state")
+        p0, p1 = f32(p0), f32(p1)
+        rows = cfg.n_stages - 1
+        est_jac = torch.empty(rows * B * D * D, dtype=torch.float32, device=dev)
+        est_div = torch.empty(rows * B, dtype=torch.float32, device=dev)
+        est_ws = torch.empty(max(1, int(_native.lib().ff_trace_workspace_floats(code, D, r, rows * B))), dtype=torch.float32, device=dev)
+        if POISON is not None:
+            est_jac.fill_(POISON), est_div.fill_(POISON), est_ws.fill_(POISON)
+        keep.extend([p0, p1, est_jac, est_div, est_ws])
+        b.est_kind, b.est_r, b.est_m = code, r, m
+        b.est_probes0, b.est_probes1 = p0.data_ptr(), (0 if p1 is None else p1.data_ptr())
+        b.est_jac, b.est_div, b.est_workspace = est_jac.data_ptr(), est_div.data_ptr(), est_ws.data_ptr()
     b.n_passes = P
     for j, (first, count) in enumerate(passes):
         b.pass_first[j], b.pass_count[j] = first, count

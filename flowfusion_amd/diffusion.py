@@ -10,9 +10,9 @@ What is native (csrc/ff_mlp_ode.hpp through the C ABI in include/flowfusion_amd.
 ``ScoreModel.sample_ode_from_base``, ``solve_odes_forward`` / ``log_prob`` (Hutchinson probe or
 exact trace) and ``sample_sde``, for an ``MLP`` score network with SiLU activations and a
 fixed-grid ``method`` (``euler``, ``midpoint``, ``heun3``, ``rk4`` + ``options={"step_size": h}``) or
-the reference's default adaptive ``dopri5`` (step control on the device, device_adaptive.py; host controller: adaptive.py).
-Anything else on those methods (other adaptive solvers, Hutch++/XTrace, CPU tensors) raises: there is no
-eager/CPU fallback behind them.  The small pointwise members (``MLP.forward``, ``score``,
+the reference's default adaptive ``dopri5`` (step control on the device, device_adaptive.py; host controller: adaptive.py),
+the divergence by Hutchinson probe, exact trace or the Hutch++ / XTrace estimators (csrc/ff_trace.hip).
+CPU tensors raise: there is no eager/CPU fallback behind these methods.  The small pointwise members (``MLP.forward``, ``score``,
 ``ode_drift``, the SDE schedule functions) are ordinary torch code, used by training code and to
 build the per-evaluation tables on the host.  Training losses and the adjoint branches of the
 reference are out of scope.
@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import Optional
 
 import torch
@@ -247,19 +248,26 @@ class ScoreModel(nn.Module):
 
     def _estimate_divergence(self, A, x):
         """Divergence estimate [B] from A[b] = J[b]^T with the stored probes (drawn afresh, like the reference's
-        fallback :350-353, :415-416, when none of the right shape are stored)."""
+        fallback :350-353, :415-416, when none of the right shape are stored).  On the GPU the estimate is one launch of
+        ff_trace_estimate (csrc/ff_trace.hip); CPU tensors -- ``forward`` in training code, the tests' emulator -- and
+        ``FF_TORCH_ESTIMATOR=1`` (A/B runs) take the torch statement of the same formulas (trace_estimators.py)."""
         B, D = x.shape
         (r, m), mx = self._probe_counts(D)
+        native = A.is_cuda and A.dtype == torch.float32 and os.environ.get("FF_TORCH_ESTIMATOR", "") in ("", "0")
         if self.hutchpp:
             S, G = getattr(self, "S", None), getattr(self, "G", None)
             if S is None or tuple(S.shape) != (r, B, D):
                 S = trace_estimators.draw_probes(r, x)
             if G is None or tuple(G.shape) != (m, B, D):
                 G = trace_estimators.draw_probes(m, x)
+            if native:
+                return _native.trace_estimate(A.unsqueeze(0), "hutchpp", (S, G))[0]
             return trace_estimators.hutchpp(A, S.to(A.device), G.to(A.device))
         O = getattr(self, "O", None)
         if O is None or tuple(O.shape) != (mx, B, D):
             O = trace_estimators.draw_probes(mx, x)
+        if native:
+            return _native.trace_estimate(A.unsqueeze(0), "xtrace", (O,))[0]
         return trace_estimators.xtrace(A, O.to(A.device))
 
     # -- any other `model=` module: native stepping around the module's own forward (generic.py) -------------
@@ -675,10 +683,12 @@ class ScoreModel(nn.Module):
         return xT, dlogp.view(-1, 1)
 
     def _solve_with_estimator(self, x0, conditional, atol, rtol, method, options):
-        """Hutch++ / XTrace log-density solve: the estimators factorise a sketch of the Jacobian at every
-        evaluation, so the table is run row by row (host_stepper.py) -- each row one fused launch that returns
-        the right-hand side and its whole Jacobian -- instead of in a single launch.  Probes are drawn once per
-        solve on the state's device, as the reference does (:703-719)."""
+        """Hutch++ / XTrace log-density solve.  The state never depends on the divergence, so the launches are those of the
+        exact trace with the Jacobian of every evaluation row recorded (ff_ode_args.jac_all); the estimates of all rows
+        come from ONE launch (ff_trace_estimate, csrc/ff_trace.hip) and are combined with the tableau's weights.  The
+        adaptive methods run with the step control on the device like every other solve (device_adaptive.py); the host
+        controller with one launch per right-hand side (host_stepper.py) stays for what that cannot describe.  Probes are
+        drawn once per solve on the state's device, as the reference does (:703-719)."""
         net = self._net()
         if net.precision != "f32":
             raise NotImplementedError(f"precision={net.precision!r}: the Hutch++ / XTrace estimators need the Jacobian output of the "
@@ -691,33 +701,40 @@ class ScoreModel(nn.Module):
         if self.hutchpp:
             self.S = trace_estimators.draw_probes(r, x0)
             self.G = trace_estimators.draw_probes(m, x0)
+            kind, probes = "hutchpp", (self.S, self.G)
         else:
             # the reference stores max(1, xt_vecs) probes and redraws inside forward when that exceeds D (:719, :409-416)
             self.O = trace_estimators.draw_probes(mx, x0)
+            kind, probes = "xtrace", (self.O,)
         x = x0.detach().to(torch.float32).contiguous()
-        stepper = host_stepper.RowStepper(net, x.device, conditional, lambda A: self._estimate_divergence(A, x))
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
         if method in solvers.ALL_ADAPTIVE:
+            spec = self._device_schedule(x.device) if method in solvers.NATIVE_ADAPTIVE else None
+            if device_adaptive.supported(spec, x, net, MODE_EXACT) and \
+                    device_adaptive.estimator_bytes(net, method, B, kind, probes) <= self._estimator_budget(x.device):
+                y, lp, stats = device_adaptive.solve(net, spec, 1.0, MODE_EXACT, x, float(t_span[0]), float(t_span[1]), rtol, atol,
+                                                     options, method, cond=conditional, estimator=(kind, probes))
+                self.last_solver_stats = stats
+                return y, lp.view(-1, 1)
+            stepper = host_stepper.RowStepper(net, x.device, conditional, lambda A: self._estimate_divergence(A, x))
             host = self._schedule_inputs()
             sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             solver = adaptive.make_solver(stepper.make_step(sched, 1.0), True, rtol, atol, options, method=method)
             y, lp = solver.integrate(float(t_span[0]), float(t_span[1]), x, torch.zeros(B, device=x.device))
             self.last_solver_stats = {"attempts": solver.n_attempts, "accepted": solver.n_accepted}
         else:
-            # fixed grid: one launch per tangent pass records every row's Jacobian; the estimator then runs for all
-            # rows at once with each sample's probes repeated over the rows
-            def div_rows(A, lo, hi):
-                n, b = A.shape[0], A.shape[1]
-                rep = lambda P: P[:, lo:hi].unsqueeze(1).expand(P.shape[0], n, b, D).reshape(P.shape[0], n * b, D)
-                flat = A.reshape(n * b, D, D)
-                if self.hutchpp:
-                    est = trace_estimators.hutchpp(flat, rep(self.S.to(A.device)), rep(self.G.to(A.device)))
-                else:
-                    est = trace_estimators.xtrace(flat, rep(self.O.to(A.device)))
-                return est.reshape(n, b)
+            # fixed grid: one launch per tangent pass records every row's Jacobian, one launch estimates all of them
+            stepper = host_stepper.RowStepper(net, x.device, conditional, None)
+            div_rows = lambda A, lo, hi: _native.trace_estimate(A, kind, tuple(P[:, lo:hi] for P in probes))
             y, lp = stepper.run_table_recorded(x, self._ode_table(t_span, method, options, MODE_EXACT), div_rows,
                                                cond=conditional)
         return y, lp.view(-1, 1)
+
+    @staticmethod
+    def _estimator_budget(device) -> int:
+        """Bytes the recorded Jacobians of an attempted step may take: half of what the device has free right now."""
+        free, _ = torch.cuda.mem_get_info(device)
+        return free // 2
 
     @torch.no_grad()
     def log_prob(self, x0_samples, conditional=None, atol=1e-4, rtol=1e-4, method="dopri5",

@@ -328,6 +328,39 @@ size_t ff_scaled_rms_workspace_bytes(void);
 int ff_scaled_rms(const ff_norm_term* terms, int32_t n_terms, float atol, float rtol, const float* check,
                   int64_t n_check, float* out, void* workspace, void* hip_stream);
 
+/* ---- Hutch++ / XTrace divergence estimates from recorded Jacobians (csrc/ff_trace.hip, csrc/ff_trace_est.h) ----
+ *
+ * Replaces the two estimator branches of ScoreModel.forward, diffusion.py:336-400 (Hutch++) and :402-481 (XTrace), for
+ * every right-hand-side evaluation of a launch at once: with ff_ode_args.jac_all = 1 a fused FF_MODE_EXACT launch leaves
+ * A[e][b] = J^T of every evaluation row e and sample b; one launch of this kernel returns the estimates
+ *     out[e][b] = hutchpp(A[e][b]; S[:, b], G[:, b])   or   xtrace(A[e][b]; O[:, b])
+ * with the probes laid out as the reference stores them ([n_probes][batch][dim], entries +-1; drawn once per solve,
+ * diffusion.py:703-719).  The QR behind both is LAPACK's Householder scheme, what `torch.linalg.qr` (:378, :441) runs on
+ * the reference's CPU path.  All pointers are DEVICE pointers (HOST pointers for ff_trace_estimate_host).
+ */
+#define FF_TRACE_HUTCHPP 1
+#define FF_TRACE_XTRACE  2
+typedef struct ff_trace_args {
+    int32_t kind;            /* FF_TRACE_*                                                                     */
+    int32_t dim;             /* D                                                                               */
+    int32_t n_rows;          /* evaluation rows recorded in `jac`                                               */
+    int32_t r;               /* Hutch++: sketch probes S (`hpp_rank`, <= D); XTrace: probes O (`xt_vecs`, <= D)  */
+    int32_t m;               /* Hutch++: residual probes G (`hpp_vecs`, >= 1); XTrace: unused                   */
+    int32_t reserved;
+    int64_t batch;
+    const float* jac;        /* [n_rows][batch][D][D]: row j of a matrix is J^T e_j (ff_ode_args.jac_out)        */
+    const float* probes0;    /* S or O: [r][batch][D]                                                           */
+    const float* probes1;    /* G: [m][batch][D], or NULL (XTrace)                                              */
+    float*       out;        /* [n_rows][batch]                                                                 */
+    float*       workspace;  /* ff_trace_workspace_floats(kind, dim, r, n_rows * batch) floats                   */
+    const int32_t* gate;     /* optional DEVICE word: 0 = the launch does nothing (see ff_ode_args.gate)         */
+} ff_trace_args;
+size_t ff_trace_workspace_floats(int32_t kind, int32_t dim, int32_t r, int64_t items);
+int ff_trace_estimate(const ff_trace_args* args, void* hip_stream);
+/* The same arithmetic on the HOST (tests without a GPU): HOST pointers; `workspace` holds
+ * ff_trace_workspace_floats(kind, dim, r, 1) floats; `gate` is ignored. */
+int ff_trace_estimate_host(const ff_trace_args* args);
+
 /* ---- adaptive embedded Runge-Kutta solves with the step control ON THE DEVICE (csrc/ff_adaptive.hip) ---------
  *
  * Replaces `odeint(func, state, t, method="dopri5" | "bosh3" | "fehlberg2" | "adaptive_heun", rtol=, atol=, options=)`
@@ -435,6 +468,20 @@ typedef struct ff_adapt_buffers {
     double* exchange_sums;
     int (*exchange)(void* user, void* hip_stream);
     void* exchange_user;
+    /* Divergence by a Hutch++ / XTrace ESTIMATE instead of the exact trace (ScoreModel(hutchpp=True) / (xtrace=True),
+     * diffusion.py:336-481; FF_MODE_EXACT only).  The state never depends on the divergence, so an attempted step stays
+     * the fused launch(es) of the exact trace -- now recording the Jacobian of every evaluation row into est_jac -- followed
+     * by ONE ff_trace_estimate launch over all rows and one launch that combines the rows' estimates with the attempt's
+     * tail coefficients into aux_lp[0..3] (proposal, last stage, midpoint, error estimate), the same linear combinations
+     * the fused kernel takes of its own divergence slots.  est_kind = 0: the exact trace. */
+    int32_t est_kind;            /* 0 or FF_TRACE_*                                                          */
+    int32_t est_r, est_m;        /* ff_trace_args.r / .m                                                     */
+    int32_t est_reserved;
+    const float* est_probes0;    /* ff_trace_args.probes0 / probes1                                          */
+    const float* est_probes1;
+    float* est_jac;              /* [n_stages - 1][B][D][D]                                                  */
+    float* est_div;              /* [n_stages - 1][B]                                                        */
+    float* est_workspace;        /* ff_trace_workspace_floats(est_kind, D, est_r, (n_stages - 1) * B) floats  */
 } ff_adapt_buffers;
 #define FF_EXCHANGE_DOUBLES 8
 

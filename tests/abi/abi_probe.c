@@ -53,6 +53,13 @@ int main(void)
     OFF(ff_adapt_buffers, norm_workspace); OFF(ff_adapt_buffers, norm_only); OFF(ff_adapt_buffers, norm_only_n);
     OFF(ff_adapt_buffers, n_passes); OFF(ff_adapt_buffers, pass_first); OFF(ff_adapt_buffers, pass_count);
     OFF(ff_adapt_buffers, exchange_sums); OFF(ff_adapt_buffers, exchange); OFF(ff_adapt_buffers, exchange_user);
+    OFF(ff_adapt_buffers, est_kind); OFF(ff_adapt_buffers, est_r); OFF(ff_adapt_buffers, est_m); OFF(ff_adapt_buffers, est_reserved);
+    OFF(ff_adapt_buffers, est_probes0); OFF(ff_adapt_buffers, est_probes1); OFF(ff_adapt_buffers, est_jac);
+    OFF(ff_adapt_buffers, est_div); OFF(ff_adapt_buffers, est_workspace);
+    SZ(ff_trace_args);
+    OFF(ff_trace_args, kind); OFF(ff_trace_args, dim); OFF(ff_trace_args, n_rows); OFF(ff_trace_args, r); OFF(ff_trace_args, m);
+    OFF(ff_trace_args, reserved); OFF(ff_trace_args, batch); OFF(ff_trace_args, jac); OFF(ff_trace_args, probes0);
+    OFF(ff_trace_args, probes1); OFF(ff_trace_args, out); OFF(ff_trace_args, workspace); OFF(ff_trace_args, gate);
 
     /* plan + packed size for BASELINE config 2's network, from C */
     const int hidden[4] = {256, 256, 256, 256};
@@ -66,6 +73,18 @@ int main(void)
     ff_ode_args a = {0};
     printf("nullargs rc %d\n", ff_mlp_ode_launch(&plan, &a, NULL));
     printf("nulladapt rc %d\n", ff_mlp_ode_adaptive(&plan, &a, NULL, NULL, 0.0, 1.0, FF_ADAPT_START, 1, NULL));
+    {   /* Hutch++ with a full-rank sketch IS the trace: 2 x 2, S = (e1 + e2, e1 - e2), from C without a GPU */
+        const float A[4] = {1.f, 2.f, 3.f, 4.f}, S[4] = {1.f, 1.f, 1.f, -1.f}, G[2] = {1.f, -1.f};
+        float out = 0.f, ws[16];
+        ff_trace_args t = {0};
+        t.kind = FF_TRACE_HUTCHPP; t.dim = 2; t.n_rows = 1; t.r = 2; t.m = 1; t.batch = 1;
+        t.jac = A; t.probes0 = S; t.probes1 = G; t.out = &out; t.workspace = ws;
+        printf("tracews %zu\n", ff_trace_workspace_floats(FF_TRACE_HUTCHPP, 2, 2, 1));
+        rc = ff_trace_estimate_host(&t);
+        printf("trace rc %d value %.5f\n", rc, (double)out);
+        t.r = 3;
+        printf("badtrace rc %d\n", ff_trace_estimate_host(&t));
+    }
     printf("version %s\n", ff_version());
     return 0;
 }

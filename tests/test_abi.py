@@ -75,6 +75,7 @@ def test_header_is_c11_and_layouts_match_both_ctypes_mirrors(tmp_path, built_lib
         "ff_adapt_state": (_native.AdaptState,),
         "ff_adapt_config": (_native.AdaptConfig,),
         "ff_adapt_buffers": (_native.AdaptBuffers,),
+        "ff_trace_args": (_native.TraceArgs,),
     }
     for cname, structs in mirrors.items():
         fields_c = {f for (s, f) in offsets if s == cname}
@@ -91,6 +92,8 @@ def test_header_is_c11_and_layouts_match_both_ctypes_mirrors(tmp_path, built_lib
     assert other["spw"].split()[1] == "64"
     assert other["badmode"].split()[2] == "-1" and other["nullargs"].split()[2] == "-1"
     assert other["nulladapt"].split()[2] == "-1"
+    assert other["trace"].split()[2] == "0" and abs(float(other["trace"].split()[4]) - 5.0) < 1e-5      # tr [[1, 2], [3, 4]]
+    assert int(other["tracews"].split()[1]) <= 16 and other["badtrace"].split()[2] == "-1"
     assert "gfx950" in other["version"]
 
 

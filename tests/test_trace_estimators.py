@@ -166,3 +166,61 @@ def test_thin_qr_follows_lapack():
     S6[3, 2] = S6[1, 2]
     est = TE.hutchpp(A, S6, G)
     assert (est - torch.diagonal(A, 0, 1, 2).sum(-1)).abs().max() < 1e-9
+
+
+# ---- the estimators in C (csrc/ff_trace_est.h: the arithmetic of the gfx950 kernel, run on the host) ----------------
+@pytest.mark.parametrize("name", CASES)
+def test_native_estimators_match_reference_fixtures(name, built_library):
+    """ff_trace_estimate_host on the Jacobians of the product's plain-torch drift against the estimates the reference's
+    ScoreModel.forward produced with the same probes (diffusion.py:336-481), all three stored times in one call."""
+    meta, a = load_golden(name)
+    sm = score_model(meta, a)
+    x, cond = a["x"], a.get("cond")
+    ok_s, ok_o = well_posed(a["S"]), well_posed(a["O"])
+    rows = []
+    for i in range(3):
+        t = a[f"t{i}"]
+        J = torch.autograd.functional.jacobian(lambda v: sm.ode_drift(t, v, conditional=cond).sum(0), x, vectorize=True)
+        rows.append(J.permute(1, 2, 0).contiguous())              # A[b, j, i] = d xdot_i / d x_j
+    A = torch.stack(rows)                                         # [3, B, D, D]
+    hpp = _native.trace_estimate(A, "hutchpp", (a["S"], a["G"]), host=True)
+    xt = _native.trace_estimate(A, "xtrace", (a["O"],), host=True)
+    for i in range(3):
+        _close(hpp[i], a[f"div_hpp_{i}"], ok_s)
+        _close(xt[i], a[f"div_xt_{i}"], ok_o)
+
+
+def test_native_estimators_match_the_torch_statement(built_library):
+    """... and against trace_estimators.py in float64 on random matrices: every shape class (one probe, several, as many
+    as dimensions, more residual probes than dimensions, one dimension), several evaluation rows per call."""
+    torch.manual_seed(11)
+    for D, r, m, B, n in ((2, 1, 1, 50, 3), (16, 1, 1, 20, 6), (5, 2, 3, 10, 2), (32, 3, 2, 10, 1), (16, 16, 1, 8, 1),
+                          (3, 2, 7, 11, 2), (1, 1, 2, 5, 1), (40, 8, 4, 3, 2)):
+        A = torch.randn(n, B, D, D)
+        S, G = torch.sign(torch.randn(r, B, D)), torch.sign(torch.randn(m, B, D))
+        rep = lambda P: P.unsqueeze(1).expand(P.shape[0], n, B, D).reshape(P.shape[0], n * B, D).double()
+        ok = well_posed(S).repeat(n)
+        flat = A.reshape(n * B, D, D).double()
+        scale = max(1.0, float(A.abs().sum(dim=(2, 3)).max()))     # the estimates are sums of D^2 products
+        want = TE.hutchpp(flat, rep(S), rep(G))
+        got = _native.trace_estimate(A, "hutchpp", (S, G), host=True).reshape(-1).double()
+        assert float((got - want)[ok].abs().max()) < 2e-6 * scale, (D, r, m)
+        want = TE.xtrace(flat, rep(S))
+        got = _native.trace_estimate(A, "xtrace", (S,), host=True).reshape(-1).double()
+        assert float((got - want)[ok].abs().max()) < 2e-6 * scale * max(1, r), (D, r)
+        if r == D:                                                 # the sketch spans everything: Hutch++ IS the trace
+            tr = torch.diagonal(A, 0, 2, 3).sum(-1).reshape(-1).double()
+            est = _native.trace_estimate(A, "hutchpp", (S, G), host=True).reshape(-1).double()
+            assert float((est - tr)[ok].abs().max()) < 2e-6 * scale
+    # a column with nothing below the diagonal (H = I) and a rank-deficient sketch at full rank request
+    A = torch.randn(1, 4, 3, 3)
+    A[0, 0, 1:, :] = 0.0
+    S = torch.sign(torch.randn(3, 4, 3))
+    S[2, 1] = -S[0, 1]
+    G = torch.sign(torch.randn(1, 4, 3))
+    est = _native.trace_estimate(A, "hutchpp", (S, G), host=True)[0]
+    assert torch.isfinite(est).all()
+    with pytest.raises(RuntimeError, match="do not match"):
+        _native.trace_estimate(A, "hutchpp", (S[:, :2], G), host=True)
+    with pytest.raises(ValueError, match="expected 'hutchpp' or 'xtrace'"):
+        _native.trace_estimate(A, "hutch", (S,), host=True)
