@@ -319,7 +319,7 @@ def extra_configs(device):
     nb.hutch = False
     # Hutch++ / XTrace with the notebook's arguments (one probe each: hpp_rank = hpp_vecs = xt_vecs = 1; everything else at
     # its default): the fused attempt records every row's Jacobian, one launch estimates them, the controller stays on the
-    # device.  FF_HOST_CONTROLLER=1 is rounds 1-3's route (a launch per right-hand side, torch estimator, host controller).
+    # device.  FF_HOST_CONTROLLER=1 + FF_TORCH_ESTIMATOR=1 is rounds 1-3's route (a launch per right-hand side, torch estimator, host controller).
     for name, attr, ref_s, cell in (("diffusion_log_prob_hutchpp_50000", "hutchpp", 46.28, "demo_diffusion.ipynb:455"),
                                     ("diffusion_log_prob_xtrace_50000", "xtrace", 34.35, "demo_diffusion.ipynb:456")):
         setattr(nb, attr, True)
@@ -327,13 +327,14 @@ def extra_configs(device):
             nb.log_prob(xb[:512].contiguous())
             ms = 1e3 * min(_timed(lambda: nb.log_prob(xb), device)[1] for _ in range(3))
             nbk[name] = {"ms": ms, **dict(nb.last_solver_stats), "reference_notebook_s": ref_s, "reference_cell": cell}
-            os.environ["FF_HOST_CONTROLLER"] = "1"
+            os.environ["FF_HOST_CONTROLLER"] = os.environ["FF_TORCH_ESTIMATOR"] = "1"
             nb.log_prob(xb[:512].contiguous())
             nbk[name]["ms_host_route_of_rounds_1_to_3"] = 1e3 * _timed(lambda: nb.log_prob(xb), device)[1]
         except RuntimeError as e:
             nbk[name] = {"error": str(e)}
         finally:
             os.environ.pop("FF_HOST_CONTROLLER", None)
+            os.environ.pop("FF_TORCH_ESTIMATOR", None)
             setattr(nb, attr, False)
     torch.manual_seed(0)
     fl = Fm.ODEFlow(target_dimension=2, hidden_units=[128, 128, 128]).eval().to(device)      # demo_flow.ipynb cell 7

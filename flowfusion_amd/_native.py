@@ -222,6 +222,8 @@ def lib() -> ctypes.CDLL:
     L.ff_mlp_samples_per_workgroup.restype = ctypes.c_int
     L.ff_mlp_samples_per_workgroup.argtypes = [ctypes.POINTER(PlanStruct), ctypes.c_int]
     L.ff_last_hip_error.restype = ctypes.c_int
+    L.ff_mlp_launch_kind.restype = ctypes.c_int
+    L.ff_mlp_launch_kind.argtypes = [ctypes.POINTER(PlanStruct), ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
     L.ff_normal_fill.restype = ctypes.c_int
     L.ff_normal_fill.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64, ctypes.c_int64,
                                  ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p]
@@ -305,6 +307,17 @@ def kernel_name(plan: PlanStruct) -> str:
     """ff_plan_kernel_name: the instantiation a plan selects."""
     n = lib().ff_plan_kernel_name(ctypes.byref(plan))
     return n.decode() if n else "?"
+
+
+LAUNCH_ONE_WAVE, LAUNCH_TWIN, LAUNCH_ONE_WAVE_AND_TWIN = 0, 1, 2      # FF_LAUNCH_*
+
+
+def launch_kind(plan: PlanStruct, batch: int, mode: int, tangent_count: int = 0, jac_out: bool = False) -> int:
+    """ff_mlp_launch_kind: which kernel(s) a launch of ``batch`` samples takes (LAUNCH_*)."""
+    rc = int(lib().ff_mlp_launch_kind(ctypes.byref(plan), batch, mode, tangent_count, int(jac_out)))
+    if rc < 0:
+        raise _err(rc, "ff_mlp_launch_kind")
+    return rc
 
 
 def samples_per_workgroup(plan: PlanStruct, mode: int) -> int:

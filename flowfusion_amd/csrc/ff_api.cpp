@@ -428,6 +428,72 @@ static int launch_split(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* h
     return FF_OK;
 }
 
+// Which kernel(s) serve a launch of `tiles` tiles (16 or 32 columns each) of an f32 plan.
+//
+// Small batches: when the tiles of the batch would leave at least half the chip's 1024 SIMDs without one, the
+// cooperative twin (one tile per WORKGROUP, the layer's rows split over its four wavefronts) finishes an evaluation
+// in about a third of the time.  Same packed weights, bitwise the same results.  FF_COOP=0 / 1 pins the choice.
+// One rule for whole launches and for tails (below), fitted to measurements at widths 128 / 256 / 512 (scratch/tail_split.py,
+// scratch/tail_margin.py, scratch/coop_threshold.py; in units of a full round of the one-wavefront kernel):
+//   one-wavefront kernel, n tiles:  ceil(n / 1024) / wps      (n tiles run with that many wavefronts per SIMD; a wavefront
+//                                                              does not finish sooner for having fewer neighbours)
+//   twin, n tiles:                  max(least, c0 + n / (0.95 chip)),  chip = 1024 wps tiles in flight,
+//                                   c0 = 0.10 (0.20 at one wavefront per SIMD), least = 0.22 / 0.30 / 0.35 for wps = 3 / 2 / 1
+// The twin serves whatever it is faster at.
+// The tail of a launch.  The chip runs 1024 * wps tiles at once; the tiles left over after the full rounds run as a last
+// round with w = ceil(leftover / 1024) wavefronts per SIMD, which takes w / wps of a full round's time (measured: the
+// dispatcher fills SIMDs evenly, a wavefront does not finish sooner for having fewer neighbours than wps allows).
+// The cooperative twin -- a tile per workgroup, bitwise the same results -- gets through about 0.8-0.9 of a chip's worth
+// of tiles in a round's time and never needs less than ~0.3 of it.  Whenever that is the shorter of the two, the
+// leftover rows go to the twin as a second launch (scratch/tail_split.py: up to +34 % just above a whole number of
+// rounds, +5 % at eight rounds).  FF_TAIL_SPLIT=0 switches it off (A/B runs, tests).
+struct LaunchChoice {
+    bool coop;                 // the main launch is the cooperative twin (or the wide catch-all)
+    long long main_tiles;      // tiles of the main launch
+    long long tail_tiles;      // tiles of a second launch on the twin (0 = none)
+};
+
+static LaunchChoice choose_launch(const ff::KernelEntry& k, long long tiles, bool jac_out)
+{
+    const long long chip = 1024ll * (k.wps > 0 ? k.wps : 1);
+    auto twin_wins = [&](long long n) {
+        const int wps = k.wps > 0 ? k.wps : 1;
+        const double one_wave = (double)((n + 1023) / 1024) / (double)wps;
+        const double least = wps >= 3 ? 0.22 : (wps == 2 ? 0.30 : 0.35);
+        const double line = (wps == 1 ? 0.20 : 0.10) + n / (0.95 * (double)chip);
+        return (line > least ? line : least) < one_wave;
+    };
+    bool coop = k.launch_coop != nullptr && tiles <= chip && twin_wins(tiles);
+    if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
+    if (k.launch == nullptr) coop = true;                  // wide catch-all: cooperative at every batch size, one exchange buffer
+    long long tail_tiles = 0;
+    if (!coop && k.launch_coop != nullptr && k.wps > 0 && !jac_out) {
+        const long long rem = tiles % chip;
+        const char* pin = getenv("FF_TAIL_SPLIT");
+        if (tiles > chip && rem > 0 && !(pin && atoi(pin) == 0)) {
+            bool split = twin_wins(rem);
+            if (const char* m = getenv("FF_TAIL_MAX")) split = rem <= atoll(m);          // (experiments: scratch/tail_split.py)
+            if (split) tail_tiles = rem;
+        }
+    }
+    return LaunchChoice{coop, tiles - tail_tiles, tail_tiles};
+}
+
+// What ff_mlp_ode_launch would enqueue for `batch` samples in `mode`: FF_LAUNCH_* (see the header).
+extern "C" int ff_mlp_launch_kind(const ff_mlp_plan_t* plan, int64_t batch, int32_t mode, int32_t tangent_count, int32_t jac_out)
+{
+    if (plan_ok_split(plan)) return FF_LAUNCH_ONE_WAVE;
+    if (!plan_ok(plan) || batch < 0) return FF_ERR_BADARG;
+    int nt, unit;
+    const int rc = tangents_of_mode(mode, plan->dim, plan->tile, &nt, &unit);
+    if (rc) return rc;
+    if (mode == FF_MODE_EXACT && tangent_count > 0) nt = tangent_count;
+    if (nt + 1 > plan->tile) return FF_ERR_BADARG;
+    const long long spt = plan->tile / (1 + nt);
+    const LaunchChoice ch = choose_launch(ff::g_kernels[plan->kernel_id], (batch + spt - 1) / spt, jac_out != 0);
+    return ch.coop ? FF_LAUNCH_TWIN : (ch.tail_tiles ? FF_LAUNCH_ONE_WAVE_AND_TWIN : FF_LAUNCH_ONE_WAVE);
+}
+
 extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a, void* hip_stream)
 {
     if (a && plan_ok_split(plan)) return launch_split(plan, a, hip_stream);
@@ -474,47 +540,10 @@ extern "C" int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* a
     if ((size_t)(a->n_evals + 2) * ka.etab_stride * 4 > 0x7fffffffull) return FF_ERR_UNSUPPORTED;
     ka.wpack_floats = (int)L.total_floats;
 
-    // Small batches: when the tiles of the batch would leave at least half the chip's 1024 SIMDs without one, the
-    // cooperative twin (one tile per WORKGROUP, the layer's rows split over its four wavefronts) finishes an evaluation
-    // in about a third of the time.  Same packed weights, bitwise the same results.  FF_COOP=0 / 1 pins the choice.
     const long long spt = plan->tile / (1 + nt);           // samples per tile
-    const long long tiles = (a->batch + spt - 1) / spt;
-    // One rule for whole launches and for tails (below), fitted to measurements at widths 128 / 256 / 512 (scratch/tail_split.py,
-    // scratch/tail_margin.py, scratch/coop_threshold.py; in units of a full round of the one-wavefront kernel):
-    //   one-wavefront kernel, n tiles:  ceil(n / 1024) / wps      (n tiles run with that many wavefronts per SIMD; a wavefront
-    //                                                              does not finish sooner for having fewer neighbours)
-    //   twin, n tiles:                  max(least, c0 + n / (0.95 chip)),  chip = 1024 wps tiles in flight,
-    //                                   c0 = 0.10 (0.20 at one wavefront per SIMD), least = 0.22 / 0.30 / 0.35 for wps = 3 / 2 / 1
-    // The twin serves whatever it is faster at.
-    const long long chip = 1024ll * (k.wps > 0 ? k.wps : 1);
-    auto twin_wins = [&](long long n) {
-        const int wps = k.wps > 0 ? k.wps : 1;
-        const double one_wave = (double)((n + 1023) / 1024) / (double)wps;
-        const double least = wps >= 3 ? 0.22 : (wps == 2 ? 0.30 : 0.35);
-        const double line = (wps == 1 ? 0.20 : 0.10) + n / (0.95 * (double)chip);
-        return (line > least ? line : least) < one_wave;
-    };
-    bool coop = k.launch_coop != nullptr && tiles <= chip && twin_wins(tiles);
-    if (const char* pin = getenv("FF_COOP")) coop = k.launch_coop != nullptr && atoi(pin) != 0;
-    const bool wide = k.launch == nullptr;                 // wide catch-all: cooperative at every batch size, one exchange buffer
-    if (wide) coop = true;
-    // The tail of a launch.  The chip runs 1024 * wps tiles at once; the tiles left over after the full rounds run as a last
-    // round with w = ceil(leftover / 1024) wavefronts per SIMD, which takes w / wps of a full round's time (measured: the
-    // dispatcher fills SIMDs evenly, a wavefront does not finish sooner for having fewer neighbours than wps allows).
-    // The cooperative twin -- a tile per workgroup, bitwise the same results -- gets through about 0.8-0.9 of a chip's worth
-    // of tiles in a round's time and never needs less than ~0.3 of it.  Whenever that is the shorter of the two, the
-    // leftover rows go to the twin as a second launch (scratch/tail_split.py: up to +34 % just above a whole number of
-    // rounds, +5 % at eight rounds).  FF_TAIL_SPLIT=0 switches it off (A/B runs, tests).
-    long long tail_tiles = 0;
-    if (!coop && k.launch_coop != nullptr && k.wps > 0 && !a->jac_out) {
-        const long long rem = tiles % chip;
-        const char* pin = getenv("FF_TAIL_SPLIT");
-        if (tiles > chip && rem > 0 && !(pin && atoi(pin) == 0)) {
-            bool split = twin_wins(rem);
-            if (const char* m = getenv("FF_TAIL_MAX")) split = rem <= atoll(m);          // (experiments: scratch/tail_split.py)
-            if (split) tail_tiles = rem;
-        }
-    }
+    const LaunchChoice ch = choose_launch(k, (a->batch + spt - 1) / spt, a->jac_out != nullptr);
+    const bool coop = ch.coop, wide = k.launch == nullptr;
+    const long long tiles = ch.main_tiles + ch.tail_tiles, tail_tiles = ch.tail_tiles;
     const unsigned slots = ff::kSlots * (plan->dregs / 4) * 64 * 16;
     const unsigned kh = (plan->width / 32) * ff::tile_rb(plan->tile);                 // operand registers of a hidden layer
     const unsigned lds_coop = slots + (wide ? 1u : 2u) * (kh / 4) * 64 * 16, lds_wave = 4u * slots;

@@ -259,6 +259,15 @@ int ff_mlp_wpack(const ff_mlp_plan_t* plan, const float* const* W, const float* 
  */
 int ff_mlp_ode_launch(const ff_mlp_plan_t* plan, const ff_ode_args* args, void* hip_stream);
 
+/* Which kernel(s) ff_mlp_ode_launch enqueues for `batch` samples of a plan in `mode` (`tangent_count`: as in ff_ode_args,
+ * 0 = the mode's default; `jac_out` != 0: a launch with a Jacobian output, which is never split): the launcher's rule as a
+ * query, so that callers, benchmarks and tests can name the kernel that ran without timing it.  Honours FF_COOP /
+ * FF_TAIL_SPLIT in the environment like the launcher does.  Negative: FF_ERR_*. */
+#define FF_LAUNCH_ONE_WAVE          0   /* the one-wavefront-per-tile kernel                                         */
+#define FF_LAUNCH_TWIN              1   /* its cooperative small-batch twin (or a wide catch-all): a tile per workgroup */
+#define FF_LAUNCH_ONE_WAVE_AND_TWIN 2   /* full rounds on the first, the leftover rows on the twin (two launches)     */
+int ff_mlp_launch_kind(const ff_mlp_plan_t* plan, int64_t batch, int32_t mode, int32_t tangent_count, int32_t jac_out);
+
 /* Samples handled by one workgroup of a plan/mode (for sizing and roofline accounting). */
 int ff_mlp_samples_per_workgroup(const ff_mlp_plan_t* plan, int mode);
 

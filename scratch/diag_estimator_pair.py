@@ -37,6 +37,7 @@ def spy2(self, t0, dt, t1, *aa):
     return orig_attempt(self, t0, dt, t1, *aa)
 adaptive.Dopri5._attempt = spy2
 os.environ["FF_HOST_CONTROLLER"] = "1"
+os.environ["FF_TORCH_ESTIMATOR"] = "1"       # rounds 1-3's route proper: the torch statement of the estimator
 lh = run()
 print("attempt | device: (attempts, accepted, t_after, dt_next, ratio) | host: (t_before, dt), ratio")
 for i in range(max(len(dev_trace), len(host_trace))):

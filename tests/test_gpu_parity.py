@@ -997,7 +997,9 @@ def test_random_shapes_against_oracle():
     import os
     rnd = random.Random(int(os.environ.get("FF_SWEEP_SEED", "2024")))      # (other seeds / more cases: one-off hunts)
     kernels = set()
-    for case in range(int(os.environ.get("FF_SWEEP_CASES", "48"))):
+    relaxed = []
+    n_cases = int(os.environ.get("FF_SWEEP_CASES", "48"))
+    for case in range(n_cases):
         wmax = rnd.choice([40, 64, 100, 128, 200, 256, 384, 512])
         depth = rnd.choice([1, 2, 3, 5])
         units = [rnd.randint(max(8, wmax // 2), wmax) for _ in range(depth)]
@@ -1033,12 +1035,17 @@ def test_random_shapes_against_oracle():
         err = _logp_err(lp, lref.float())
         if err >= LOGP_TOL:
             # an ill-conditioned draw (delta_logp and the prior term cancel): the bar is then the distance of the REFERENCE'S
-            # OWN fp32 arithmetic from float64 on this case, not a fixed number (tests/sweep_diag.py replays a case)
+            # OWN fp32 arithmetic from float64 on this case (tests/sweep_diag.py replays a case) -- and never beyond
+            # north_star's 1e-4, and only for a case or two of the sweep
             so32 = O.ScoreOracle(params, {"VPSDE": O.VP, "VESDE": O.VE, "SUBVPSDE": O.SubVP}[sde](dtype=torch.float32),
                                  no_sigma=no_sigma, dtype=torch.float32)
             l32 = so32.log_prob(xd, cond, method, opts, mode, None if e is None else e.float())
-            assert err < 4 * _logp_err(l32, lref.float()), tag + (mode, err)
+            own = _logp_err(l32, lref.float())
+            assert err < min(1e-4, 4 * own), tag + (mode, err, own)
+            relaxed.append((case, mode, err, own))
         kernels.add(_native.lib().ff_kernel_name(sm._net().plan(1 if sm.hutch else 2).kernel_id))
+    print(f"\n[sweep] {len(relaxed)} of {n_cases} cases took the conditioning-aware bar (err, fp32 oracle's own err): {relaxed}")
+    assert len(relaxed) <= max(2, n_cases // 24), relaxed
     assert len(kernels) >= 16, sorted(kernels)
 
 
