@@ -412,7 +412,7 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
     from flowfusion_amd import _native
     from flowfusion_amd import flow as Fm
     from flowfusion_amd.diffusion import MLP, VESDE, ScoreModel
-    from flowfusion_amd.distributed import gather_rows, log_prob_sharded, sample_sde_sharded, shard_bounds
+    from flowfusion_amd.distributed import flow_sample_sharded, gather_rows, log_prob_sharded, sample_sde_sharded, shard_bounds
     gather_dev = device if backend == "nccl" else torch.device("cpu")
     recs, invariant = [], True
 
@@ -462,13 +462,15 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
     torch.manual_seed(0)
     f = Fm.ODEFlow(64, [512] * 5).to(device).eval()
     lo, hi = shard_bounds(rows_c4, world, rank)
-    xT = _native.normal_fill(hi - lo, 64, 2024, lo, device)
     o4 = {"step_size": 1.0 / flow_steps}
-    f.sample(xT[:64].contiguous(), method="dopri5_fixed", options=o4)
+    kw4 = {"seed": 2024, "gather": False, "method": "dopri5_fixed", "options": o4}
+    f.sample(_native.normal_fill(64, 64, 2024, lo, device), method="dopri5_fixed", options=o4)
     dist.barrier()
-    y, wall, kms = _timed(lambda: f.sample(xT, method="dopri5_fixed", options=o4), device)
+    # distributed.flow_sample_sharded: base samples drawn on the device keyed by the global row, this rank's rows integrated
+    (y, span), wall, kms = _timed(lambda: flow_sample_sharded(f, rows_c4, **kw4), device)
+    assert span == (lo, hi)
     full, gms = timed_gather(y, rows_c4)
-    head = f.sample(xT[:256].contiguous(), method="dopri5_fixed", options=o4)
+    head = f.sample(_native.normal_fill(min(256, hi - lo), 64, 2024, lo, device), method="dopri5_fixed", options=o4)
     ok4 = bool(torch.equal(head, y[:256])) and bool(torch.equal(full[lo:lo + 256].to(device), y[:256]))
     invariant &= ok4
     walls, kmss, gmss = per_rank([1e3 * wall, kms, gms])
@@ -482,8 +484,8 @@ def sharded_extras(device, world, rank, dist, backend, rows_c4, rows_c5, flow_st
                  "roofline": {"bound": "mfma", "achieved": 2.0 * mac4 * n_evals4 * (hi - lo) / (kms * 1e-3) / 1e12,
                               "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": 2.0 * mac4 * n_evals4 * (hi - lo) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                              "note": "rank 0's launch"}, "rank_invariant": ok4})
-    del f, xT, y, full, head
+                              "note": "rank 0's launch (base-sample draw on the device included in kernel_ms)"}, "rank_invariant": ok4})
+    del f, y, full, head
     # --- configs[4] ---------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
     sm5 = ScoreModel(MLP(32, 8, EMB, UNITS), VESDE()).eval().to(device)
@@ -555,6 +557,9 @@ def adaptive_exchange_extra(device, world, rank, dist, backend, rows):
                          "attempts_own_norm_only": col(4), "max_rel_diff_vs_whole_batch_solve": col(5),
                          "max_rel_diff_vs_whole_batch_solve_own_norm_only": col(6)},
             "steps_equal_whole_batch_solve_on_all_ranks": bool(same)}
+
+
+EXIT_EXTRAS_FAILED = 3     # the JSON line is printed, but a watchdog fired or an extras section carries `error`
 
 
 def run_guarded(fn, seconds, device=None):
@@ -764,7 +769,9 @@ def main():
                 rank_invariant &= ok                                   # (already MIN-reduced over the ranks inside)
             else:
                 hung = why.startswith("no answer")
-                sharded = [{"workload": "sharded BASELINE configs[2] / [3] / [4] (extras of the N > 1 run)", "error": why}]
+                sharded = [{"workload": "sharded BASELINE configs[2] / [3] / [4] (extras of the N > 1 run)", "error": why,
+                            "where": {"section": "sharded_extras: barrier / all_gather_into_tensor / all_gather / all_reduce(MIN) "
+                                                 "around configs[2], [3], [4]", "rank": rank, "watchdog_fired": hung}}]
                 rank_invariant = False
         # last of all: the adaptive path's exchange step
         if args.extras and args.adaptive_rows > 0 and not hung:
@@ -775,8 +782,10 @@ def main():
                 res, why = run_guarded(lambda: adaptive_exchange_extra(device, world, rank, dist, args.backend,
                                                                        args.adaptive_rows), args.watchdog_seconds[1], device)
             hung = res is None and why is not None and why.startswith("no answer")
-            entry = res if res is not None else {"workload": "default-argument log_prob sharded with whole-batch step control",
-                                                 "error": why}
+            entry = res if res is not None else {
+                "workload": "default-argument log_prob sharded with whole-batch step control", "error": why,
+                "where": {"section": "adaptive_exchange_extra: all_reduce of the 8 error-norm doubles (exchange hook) / barrier / "
+                                     "all_gather of the per-rank report", "rank": rank, "watchdog_fired": hung}}
             sharded = (sharded or []) + [entry]
 
     if rank == 0:
@@ -902,9 +911,12 @@ def main():
         print(json.dumps(out), flush=True)
     if multi:
         if hung or any("error" in e for e in (sharded or [])):
-            # a rank stuck in a collective (or whose peers may be) cannot tear the group down: the line is out, leave
+            # a rank stuck in a collective (or whose peers may be) cannot tear the group down: the line is out (its `error` /
+            # `where` entries say which section, on which rank), leave -- with a NON-ZERO code, so that the launcher's return
+            # code tells a run whose collective never completed from a clean one
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(EXIT_EXTRAS_FAILED)
         dist.destroy_process_group()
 
 

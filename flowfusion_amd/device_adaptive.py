@@ -229,6 +229,10 @@ def solve(net, spec: ScheduleSpec, sign: float, mode: int, x: torch.Tensor, t0: 
 
         def _hook(_user, _stream):
             try:
+                # the all-reduce is ordered with the launches around it only if it goes onto the stream the C driver
+                # enqueues on: that is torch's current stream (passed below), and it must still be when the driver calls back
+                if (_stream or 0) != torch.cuda.current_stream(dev).cuda_stream:
+                    raise RuntimeError("the exchange hook runs on a different stream than the solve's launches")
                 distributed.sum_over_ranks_(sums, group)
                 return 0
             except Exception as exc:          # noqa: BLE001 -- reported by the caller below, not through the C frame

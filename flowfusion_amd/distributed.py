@@ -12,13 +12,15 @@ squares behind each norm are all-reduced (8 doubles) when a batch is cut over ra
 from __future__ import annotations
 
 import contextlib
+import contextvars
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 # ---- the one exchange step of the path: step control of an ADAPTIVE solve over several shards of one batch -----------------
-_STEP_CONTROL = {"active": False, "group": None}
+# (a context variable: the setting belongs to the solve that entered the context, not to every host thread of the process)
+_STEP_CONTROL: contextvars.ContextVar = contextvars.ContextVar("ff_step_control", default=(False, None))
 
 
 @contextlib.contextmanager
@@ -33,17 +35,33 @@ def global_step_control(group=None):
     steps from its own rows.  Fixed-grid solves need none of this."""
     if not dist.is_initialized():
         raise RuntimeError("global_step_control needs an initialised torch.distributed process group")
-    prev = dict(_STEP_CONTROL)
-    _STEP_CONTROL.update(active=True, group=group)
+    token = _STEP_CONTROL.set((True, group))
     try:
         yield
     finally:
-        _STEP_CONTROL.update(prev)
+        _STEP_CONTROL.reset(token)
 
 
 def step_control_group():
     """(active, group) of the enclosing ``global_step_control`` context."""
-    return _STEP_CONTROL["active"], _STEP_CONTROL["group"]
+    return _STEP_CONTROL.get()
+
+
+def _is_adaptive(method) -> bool:
+    from . import solvers
+    return method in solvers.ALL_ADAPTIVE
+
+
+def _step_control(n: int, world: int, group, global_control: bool, method):
+    """The context a sharded solve runs in.  Batch-global step control needs every rank in the exchange, and an empty
+    shard has no launch to hang the exchange on: its peers would wait in the all-reduce for ever.  ``n`` and ``world``
+    are known to every rank, so every rank raises here, before anyone enters a collective."""
+    if not (global_control and world > 1 and _is_adaptive(method)):
+        return contextlib.nullcontext()
+    if n < world:
+        raise ValueError(f"global step control over {world} ranks needs at least one row per rank, the batch has {n}: use fewer "
+                         "ranks, a fixed-grid method, or global_control=False (every rank then steps from its own rows)")
+    return global_step_control(group)
 
 
 def sum_over_ranks_(values: torch.Tensor, group=None) -> torch.Tensor:
@@ -84,6 +102,9 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     sizes = shard_sizes(n_total, world)
     if world == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) != "nccl":
+        # (the gloo rehearsal of the multi-rank path -- several ranks on one card, CPU tests -- gathers through the host)
+        return gather_rows(local.cpu(), n_total, group).to(local.device)
     if len(set(sizes)) == 1:
         out = local.new_empty((n_total,) + tuple(local.shape[1:]))
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -183,7 +204,7 @@ def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional:
         rows = local_x.contiguous()
         cond = None if local_conditional is None else local_conditional.contiguous()
     extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if getattr(score_model, "hutch", False) else {}
-    with (global_step_control(group) if (global_control and world > 1) else contextlib.nullcontext()):
+    with _step_control(n, world, group, global_control, solver.get("method", "dopri5")):
         local = score_model.log_prob(rows, conditional=cond, **solver, **extra)
     if not gather:
         return local, (lo, hi)
@@ -209,8 +230,77 @@ def sample_ode_sharded(score_model, n_total: int, dim: int, seed: int = 0, condi
         if conditional is not None or local_conditional.shape[0] != hi - lo:
             raise ValueError("local_conditional must hold exactly this rank's rows (and excludes `conditional`)")
         cond = local_conditional.contiguous()
-    with (global_step_control(group) if (global_control and world > 1) else contextlib.nullcontext()):
+    with _step_control(int(n_total), world, group, global_control, solver.get("method", "dopri5")):
         local, _ = score_model.sample_ode_from_base(z, conditional=cond, **solver)
     if not gather:
         return local, (lo, hi)
     return gather_rows(local, int(n_total), group) if world > 1 else local
+
+
+# ---- the flows (flowfusion/flow.py:259-306, 386-438; 750-799, 885-941) -- BASELINE configs[3] is worded "sharded over 8xMI355X"
+def _local_rows(full, local, lo, hi, what):
+    if local is not None:
+        if full is not None or local.shape[0] != hi - lo:
+            raise ValueError(f"local_{what} must hold exactly this rank's rows [{lo}, {hi}) (and excludes `{what}`)")
+        return local.contiguous()
+    return None if full is None else full[lo:hi].contiguous()
+
+
+def flow_sample_sharded(flow, n_total: int, seed: int = 0, conditional: Optional[torch.Tensor] = None, group=None,
+                        gather: bool = True, local_conditional: Optional[torch.Tensor] = None, global_control: bool = True,
+                        **solver):
+    """``ODEFlow.sample`` / ``ConditionalODEFlow.sample`` of ``n_total`` base samples over all ranks.  The base samples
+    are standard normals of the library's counter-based stream keyed by ``seed`` and the GLOBAL row (``ff_normal_fill``):
+    every world size transports the same points and a rank only ever touches its own rows.  ``conditional`` is the raw
+    [n_total, C] tensor (every rank slices its rows) or ``local_conditional`` this rank's rows; the flow normalises it
+    itself (flow.py:771-777).  One all-gather at the end (north_star: "a single RCCL gather"; ``gather=False`` keeps the
+    shard and returns its bounds).  ``**solver`` (method, options, atol, rtol) goes to ``sample`` unchanged; under an
+    adaptive method -- the reference's default -- the step size comes from the error norm of the whole batch
+    (``global_step_control``), ``global_control=False``: from the rank's own rows."""
+    from . import _native
+    from .flow import _DEFAULT_SAMPLE_METHOD
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = int(n_total)
+    lo, hi = shard_bounds(n, world, rank)
+    dev = next(flow.parameters()).device
+    xT = _native.normal_fill(hi - lo, int(flow.target_dimension), int(seed), lo, dev)
+    cond = _local_rows(conditional, local_conditional, lo, hi, "conditional")
+    method = solver.get("method") or _DEFAULT_SAMPLE_METHOD
+    with _step_control(n, world, group, global_control, method):
+        local = flow.sample(xT, **solver) if cond is None else flow.sample(xT, cond, **solver)
+    if not gather:
+        return local, (lo, hi)
+    return gather_rows(local, n, group) if world > 1 else local
+
+
+def flow_log_prob_sharded(flow, x: Optional[torch.Tensor] = None, conditional: Optional[torch.Tensor] = None, seed: int = 0,
+                          group=None, gather: bool = True, local_x: Optional[torch.Tensor] = None,
+                          n_total: Optional[int] = None, local_conditional: Optional[torch.Tensor] = None,
+                          global_control: bool = True, **solver):
+    """``ODEFlow.log_prob`` / ``ConditionalODEFlow.log_prob`` of a [B, dim] batch over all ranks; one all-gather of the
+    [B] result at the end.  ``x`` (and ``conditional``) are the full tensors, every rank slicing its rows -- or ``local_x``
+    (and ``local_conditional``) this rank's rows already, with ``n_total`` the size of the whole batch.  With
+    ``hutchinson=True`` the probe comes from the library's counter-based stream keyed by ``seed`` and the GLOBAL row
+    (``probe="philox"``), so a row's result does not depend on the number of ranks; the exact trace (the reference's
+    default, flow.py:158-161) needs no random numbers.  Step control as in ``flow_sample_sharded``."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if (x is None) == (local_x is None):
+        raise ValueError("pass either the full batch `x` or this rank's rows `local_x` (with n_total)")
+    if x is None and n_total is None:
+        raise ValueError("local_x needs n_total")
+    n = int(x.shape[0] if x is not None else n_total)
+    lo, hi = shard_bounds(n, world, rank)
+    rows = _local_rows(x, local_x, lo, hi, "x")
+    if x is not None and local_conditional is not None:
+        raise ValueError("local_conditional goes with local_x")
+    if x is None and conditional is not None:
+        raise ValueError("local_x goes with local_conditional, not the full `conditional`")
+    cond = _local_rows(conditional, local_conditional, lo, hi, "conditional")
+    extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if solver.get("hutchinson") else {}
+    with _step_control(n, world, group, global_control, solver.get("method", "dopri5")):
+        local = flow.log_prob(rows, **solver, **extra) if cond is None else flow.log_prob(rows, cond, **solver, **extra)
+    if not gather:
+        return local, (lo, hi)
+    return gather_rows(local, n, group) if world > 1 else local

@@ -169,10 +169,32 @@ class _FlowBase(nn.Module):
                            out_scale=self.target_scale, out_shift=self.target_shift)
         return x
 
-    def _fused_forward(self, x, conditional, method, options, hutchinson, atol, rtol, raw_cond=None):
+    def _probe_rng(self, probe, seed, sample_offset, hutchinson):
+        """``probe="torch"`` (default): the +-1 probe is drawn on the CPU and moved; ``probe="philox"`` (keyword-only
+        extension, as on ScoreModel.log_prob): the signs of the library's counter-based normals keyed by ``seed`` and the
+        GLOBAL row ``sample_offset + r`` -- drawn on the device and independent of how a batch is cut into shards
+        (``distributed.flow_log_prob_sharded``)."""
+        if probe == "torch":
+            if seed is not None:
+                raise ValueError("seed= belongs to probe='philox' (the torch probe follows torch.manual_seed)")
+            return None
+        if probe != "philox":
+            raise ValueError(f"probe must be 'torch' or 'philox', not {probe!r}")
+        if not hutchinson:
+            raise ValueError("probe='philox' is the Hutchinson probe: pass hutchinson=True")
+        if seed is None:      # one draw of torch's generator, so torch.manual_seed still fixes the run
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return int(seed), int(sample_offset)
+
+    def _fused_forward(self, x, conditional, method, options, hutchinson, atol, rtol, raw_cond=None, probe_rng=None):
         t_span = torch.tensor([0.0, 1.0], dtype=torch.float32)
         mode, probe = MODE_EXACT, None
-        if hutchinson:
+        if hutchinson and probe_rng is not None:
+            mode = MODE_HUTCH
+            z = _native.normal_fill(x.shape[0], x.shape[1], probe_rng[0], probe_rng[1], x.device,
+                                    noise_index=_native.PROBE_NOISE_INDEX)
+            probe = torch.where(z >= 0, 1.0, -1.0).to(torch.float32)
+        elif hutchinson:
             mode = MODE_HUTCH
             probe = torch.sign(torch.randn(x.shape)).to(x.device)
         xT, logj = self._solve(x, t_span, method, options, mode, atol, rtol, cond=conditional, probe=probe,
@@ -226,17 +248,22 @@ class ODEFlow(_FlowBase):
         return self._fused_sample(xT, None, method, options, atol, rtol)
 
     def solve_ode_forward(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
-                          options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
-        """Integrate t: 0 -> 1 with the divergence; returns ``(xT, log_jacobian[B,1])`` (flow.py:308-384)."""
+                          options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False, *,
+                          probe: str = "torch", seed: Optional[int] = None, sample_offset: int = 0):
+        """Integrate t: 0 -> 1 with the divergence; returns ``(xT, log_jacobian[B,1])`` (flow.py:308-384).
+        ``probe`` / ``seed`` / ``sample_offset``: see ``_probe_rng``."""
         if adjoint:
             raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
-        return self._fused_forward(x, None, method, options, hutchinson, atol, rtol)
+        return self._fused_forward(x, None, method, options, hutchinson, atol, rtol,
+                                   probe_rng=self._probe_rng(probe, seed, sample_offset, hutchinson))
 
     def log_prob(self, x, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
-                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
+                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False, *,
+                 probe: str = "torch", seed: Optional[int] = None, sample_offset: int = 0):
         """Log-density of target-space points, shape [B] (flow.py:386-438)."""
         x = (x - self.target_shift) / self.target_scale
-        xT, logj = self.solve_ode_forward(x, atol, rtol, method, options, adjoint, hutchinson=hutchinson)
+        xT, logj = self.solve_ode_forward(x, atol, rtol, method, options, adjoint, hutchinson=hutchinson,
+                                          probe=probe, seed=seed, sample_offset=sample_offset)
         base = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
         return base + logj.squeeze(1) - torch.sum(torch.log(self.target_scale))
 
@@ -297,16 +324,18 @@ class ConditionalODEFlow(_FlowBase):
 
     def solve_ode_forward(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5,
                           method: str = "dopri5", options: Optional[dict] = None, adjoint: bool = False,
-                          hutchinson: bool = False):
+                          hutchinson: bool = False, *, probe: str = "torch", seed: Optional[int] = None,
+                          sample_offset: int = 0):
         if adjoint:
             raise NotImplementedError("adjoint=True (odeint_adjoint) is out of scope for the fused path")
         return self._fused_forward(x, self._norm_cond(conditional), method, options, hutchinson, atol, rtol,
-                                   raw_cond=conditional)
+                                   raw_cond=conditional, probe_rng=self._probe_rng(probe, seed, sample_offset, hutchinson))
 
     def log_prob(self, x, conditional, atol: float = 1e-5, rtol: float = 1e-5, method: str = "dopri5",
-                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False):
+                 options: Optional[dict] = None, adjoint: bool = False, hutchinson: bool = False, *,
+                 probe: str = "torch", seed: Optional[int] = None, sample_offset: int = 0):
         x = (x - self.target_shift) / self.target_scale
         xT, logj = self.solve_ode_forward(x, conditional, atol, rtol, method, options, adjoint,
-                                          hutchinson=hutchinson)
+                                          hutchinson=hutchinson, probe=probe, seed=seed, sample_offset=sample_offset)
         base = torch.sum(-0.5 * xT ** 2 - 0.5 * torch.log(self.twopi), dim=1)
         return base + logj.squeeze(1) - torch.sum(torch.log(self.target_scale))

@@ -85,6 +85,30 @@ def main():
                                      "same_steps": s_mine["attempts"] == hm.last_solver_stats["attempts"],
                                      "global": s_mine, "whole": dict(hm.last_solver_stats)}
 
+    # the flows' sharded entry points (BASELINE configs[3] is worded "sharded over 8xMI355X"): default arguments = adaptive
+    # dopri5 under the whole-batch step control; Hutchinson probe keyed by the global row
+    from flowfusion_amd.distributed import flow_log_prob_sharded, flow_sample_sharded
+    mine, span = flow_sample_sharded(f, n, seed=5, gather=False)
+    s_mine = dict(f.last_solver_stats)
+    whole = f.sample(_native.normal_fill(n, 8, 5, 0, dev))
+    out["flow_sample_sharded"] = {"span_ok": span == (lo, hi), "err": err(mine, whole[lo:hi]),
+                                  "same_steps": s_mine["attempts"] == f.last_solver_stats["attempts"]}
+    xf = torch.randn(n, 8, device=dev) * 0.7
+    mine, span = flow_log_prob_sharded(f, xf, seed=4, gather=False, hutchinson=True, atol=1e-4, rtol=1e-4)
+    s_mine = dict(f.last_solver_stats)
+    whole = f.log_prob(xf, atol=1e-4, rtol=1e-4, hutchinson=True, probe="philox", seed=4)
+    out["flow_log_prob_sharded_hutch"] = {"span_ok": span == (lo, hi), "err": err(mine, whole[lo:hi]),
+                                          "same_steps": s_mine["attempts"] == f.last_solver_stats["attempts"]}
+    gathered = flow_sample_sharded(f, n, seed=5, method="rk4", options={"step_size": 0.125})     # fixed grid + the one all-gather
+    out["flow_sample_sharded_gathered"] = bool(torch.equal(
+        gathered, f.sample(_native.normal_fill(n, 8, 5, 0, dev), method="rk4", options={"step_size": 0.125})))
+    # fewer rows than ranks under the whole-batch control: every rank raises before anyone enters a collective
+    try:
+        flow_sample_sharded(f, world - 1, seed=5)
+        out["too_few_rows_raises"] = False
+    except ValueError:
+        out["too_few_rows_raises"] = True
+
     # an empty shard cannot take part
     try:
         with global_step_control():

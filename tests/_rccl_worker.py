@@ -58,6 +58,16 @@ def main():
     out["log_prob_sharded"] = bool(torch.equal(log_prob_sharded(hm, x16, seed=9), hm.log_prob(x16, probe="philox", seed=9)))
     s = sample_sde_sharded(hm, (2000, 16), steps=10, seed=1)
     out["sample_sde_sharded"] = bool(torch.isfinite(s).all()) and tuple(s.shape) == (2000, 16)
+    from flowfusion_amd import flow as Fm
+    from flowfusion_amd.distributed import flow_log_prob_sharded, flow_sample_sharded
+    torch.manual_seed(4)
+    fl = Fm.ConditionalODEFlow(6, 2, [128, 128]).eval().to(dev)
+    cf = torch.randn(2500, 2, device=dev)
+    got = flow_sample_sharded(fl, 2500, seed=5, conditional=cf)
+    out["flow_sample_sharded"] = bool(torch.equal(got, fl.sample(_native.normal_fill(2500, 6, 5, 0, dev), cf)))
+    xf = torch.randn(2500, 6, device=dev) * 0.7
+    got = flow_log_prob_sharded(fl, xf, cf, seed=8, hutchinson=True)
+    out["flow_log_prob_sharded"] = bool(torch.equal(got, fl.log_prob(xf, cf, hutchinson=True, probe="philox", seed=8)))
     dist.barrier()
     dist.destroy_process_group()
     with open(os.path.join(os.environ["FF_RESULT_DIR"], "rccl.json"), "w") as fh:

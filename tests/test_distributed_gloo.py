@@ -185,3 +185,132 @@ def test_global_step_control_over_gloo(built_library):
         assert c["err_global"] < 2e-5, (r, c)
         assert c["err_alone"] < 5e-3, (r, c)
     assert any(tuple(c["alone"]) != tuple(c["whole"]) or c["err_alone"] > 100 * max(c["err_global"], 1e-12) for c in results.values())
+
+
+# ---- the flows' sharded entry points (BASELINE configs[3] is worded "sharded over 8xMI355X") ---------------------------
+class _RowKeyedFlow:
+    """Stand-in for ODEFlow / ConditionalODEFlow: results depend on each row's values, its conditional and -- for the
+    Hutchinson log-density -- the GLOBAL row it is told; records whether the whole-batch step control was on."""
+    target_dimension = 3
+
+    def __init__(self):
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.controlled = []
+
+    def parameters(self):
+        return iter([self.w])
+
+    def _note(self):
+        from flowfusion_amd.distributed import step_control_group
+        self.controlled.append(step_control_group()[0])
+
+    def sample(self, xT, conditional=None, **solver):
+        self._note()
+        c = 0.0 if conditional is None else conditional.sum(1, keepdim=True)
+        return torch.tanh(xT) * 2 + c + (1.0 if solver.get("method") == "rk4" else 0.0)
+
+    def log_prob(self, x, conditional=None, hutchinson=False, probe="torch", seed=None, sample_offset=0, **solver):
+        self._note()
+        assert (probe == "philox") == bool(hutchinson)
+        g = (torch.arange(x.shape[0], dtype=torch.float32) + float(sample_offset)) * (1000.0 if hutchinson else 0.0)
+        c = 0.0 if conditional is None else conditional.sum(1)
+        return x.sum(1) + g + (float(seed) if hutchinson else 0.0) + c
+
+
+def _cpu_normal_fill(batch, dim, seed, sample_offset, device, noise_index=0xFFFFFFFF, scale=1.0):
+    """ff_normal_fill's stream on the CPU (tests/_philox.py restates it): keyed by the global row, like the device's."""
+    from tests import _philox
+    return torch.from_numpy(_philox.normals(seed, sample_offset, batch, dim, [noise_index])[0].copy()) * scale
+
+
+def _flow_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowfusion_amd import _native
+        from flowfusion_amd.distributed import flow_log_prob_sharded, flow_sample_sharded
+        _native.normal_fill = _cpu_normal_fill                       # (the product draws on the device; no GPU here)
+        torch.manual_seed(0)
+        x, c = torch.randn(n, 3), torch.randn(n, 2)
+        lo, hi = shard_bounds(n, world, rank)
+        f = _RowKeyedFlow()
+        fixed = {"method": "rk4", "options": {"step_size": 0.1}}
+        base = _cpu_normal_fill(n, 3, 5, 0, "cpu")
+        ok = True
+        # sample: every world size transports the same base points; full / local conditional; gather or keep the shard
+        ok &= torch.equal(flow_sample_sharded(f, n, seed=5, **fixed), f.sample(base, **fixed))
+        ok &= torch.equal(flow_sample_sharded(f, n, seed=5, conditional=c, **fixed), f.sample(base, c, **fixed))
+        ok &= torch.equal(flow_sample_sharded(f, n, seed=5, local_conditional=c[lo:hi], **fixed), f.sample(base, c, **fixed))
+        local, span = flow_sample_sharded(f, n, seed=5, conditional=c, gather=False, **fixed)
+        ok &= span == (lo, hi) and torch.equal(local, f.sample(base, c, **fixed)[lo:hi])
+        ok &= not any(f.controlled)                                  # fixed grids: no exchange, empty shards are fine
+        # log_prob: exact trace (no random numbers) and Hutchinson (probe keyed by the global row)
+        ok &= torch.equal(flow_log_prob_sharded(f, x, c, **fixed), f.log_prob(x, c, **fixed))
+        want = f.log_prob(x, c, hutchinson=True, probe="philox", seed=9, sample_offset=0, **fixed)
+        ok &= torch.equal(flow_log_prob_sharded(f, x, c, seed=9, hutchinson=True, **fixed), want)
+        ok &= torch.equal(flow_log_prob_sharded(f, local_x=x[lo:hi], local_conditional=c[lo:hi], n_total=n, seed=9,
+                                                hutchinson=True, **fixed), want)
+        for bad in (dict(x=x, local_x=x[lo:hi]), dict(local_x=x[lo:hi]), dict(local_x=x[: hi - lo + 1], n_total=n),
+                    dict(x=x, local_conditional=c[lo:hi]), dict(local_x=x[lo:hi], n_total=n, conditional=c)):
+            try:
+                flow_log_prob_sharded(f, **bad, **fixed)
+                ok = False
+            except ValueError:
+                pass
+        # the reference's default (adaptive dopri5): whole-batch step control when every rank has a row, a ValueError on
+        # EVERY rank -- before anyone enters a collective -- when some rank has none; global_control=False needs neither
+        f.controlled.clear()
+        if n >= world:
+            flow_sample_sharded(f, n, seed=5)
+            flow_log_prob_sharded(f, x, c)
+            ok &= f.controlled == [world > 1, world > 1]
+        else:
+            for call in (lambda: flow_sample_sharded(f, n, seed=5), lambda: flow_log_prob_sharded(f, x, c),
+                         lambda: log_prob_sharded(_RowKeyedModel(), x, c, seed=9)):
+                try:
+                    call()
+                    ok = False
+                except ValueError as e:
+                    ok &= "at least one row per rank" in str(e)
+            ok &= f.controlled == []
+        f.controlled.clear()
+        got = flow_sample_sharded(f, n, seed=5, global_control=False)
+        ok &= f.controlled == [False] and torch.equal(got, f.sample(base))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 37), (8, 64), (8, 37), (8, 5)])     # even, ragged, fewer rows than ranks
+def test_flow_sharded_entry_points_over_gloo(world, n):
+    """distributed.flow_sample_sharded / flow_log_prob_sharded: base samples and the Hutchinson probe keyed by the GLOBAL
+    row, the raw conditional sliced per rank, one all-gather at the end, whole-batch step control for adaptive methods --
+    and a clean ValueError on every rank when a shard would be empty under that control (an empty shard has no launch to
+    hang the exchange on; its peers would wait in the all-reduce for ever)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flow_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=5) for _ in range(world))
+    assert results == {r: True for r in range(world)}
+
+
+def test_step_control_context_is_per_thread():
+    """`global_step_control` is a context variable: a solve on another host thread of the process does not inherit it."""
+    import threading
+    from flowfusion_amd import distributed as Dd
+    seen = {}
+    token = Dd._STEP_CONTROL.set((True, "g"))
+    try:
+        t = threading.Thread(target=lambda: seen.setdefault("other", Dd.step_control_group()))
+        t.start()
+        t.join()
+        seen["here"] = Dd.step_control_group()
+    finally:
+        Dd._STEP_CONTROL.reset(token)
+    assert seen == {"other": (False, None), "here": (True, "g")} and Dd.step_control_group() == (False, None)

@@ -451,6 +451,10 @@ def test_global_step_control_over_ranks(tmp_path):
         assert rec["sample_ode_sharded"]["span_ok"] and rec["sample_ode_sharded"]["err"] < 2e-5, rec
         lh = rec["log_prob_sharded_hutch"]
         assert lh["span_ok"] and lh["same_steps"] and lh["err"] < 2e-5, lh
+        for name in ("flow_sample_sharded", "flow_log_prob_sharded_hutch"):
+            c = rec[name]
+            assert c["span_ok"] and c["same_steps"] and c["err"] < 2e-5, (name, c)
+        assert rec["flow_sample_sharded_gathered"] is True and rec["too_few_rows_raises"] is True
     assert differs > 0        # the exchange is what made the step sequences equal
 
 

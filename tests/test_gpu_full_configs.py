@@ -479,7 +479,8 @@ def test_bench_multi_rank_branch_under_rccl_with_one_rank():
 def test_bench_line_survives_a_collective_that_never_completes():
     """The N > 1 extras run behind a watchdog: here rank 1 stays away from the last one, rank 0 waits for it in a collective
     for ever -- after the watchdog's patience (8 s in this test) rank 0 must still print the ONE line, with the headline
-    intact and an `error` entry in place of the extra, and every process must end with exit code 0."""
+    intact and an `error` entry in place of the extra (saying which section, on which rank) -- and then leave with exit code 3
+    (bench.EXIT_EXTRAS_FAILED), so that the launcher's return code tells this run from a clean one."""
     import json
     import socket
     import subprocess
@@ -495,7 +496,9 @@ def test_bench_line_survives_a_collective_that_never_completes():
            "--c4-rows", "2100", "--c4-steps", "4", "--c5-rows", "2100", "--c5-steps", "8", "--adaptive-rows", "2001",
            "--watchdog-seconds", "600", "8", "--test-desert-rank", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(root))
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import re
+    assert r.returncode != 0, (r.stdout[-1500:], r.stderr[-3000:])          # torch.distributed.run reports the failed children
+    assert re.search(r"exitcode\s*:\s*3\b", r.stderr), r.stderr[-3000:]       # ... and their code is the bench's own
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
@@ -503,6 +506,7 @@ def test_bench_line_survives_a_collective_that_never_completes():
     extras = rec["extra_configs"]
     assert len(extras) == 4 and all("error" not in e for e in extras[:3])
     assert "no answer within" in extras[3]["error"]
+    assert extras[3]["where"]["rank"] == 0 and extras[3]["where"]["watchdog_fired"] is True
 
 
 def test_offsets_beyond_two_gib():

@@ -322,3 +322,48 @@ def test_step_control_law_against_scipy(method):
             assert abs(t - ts) <= 1e-9 * max(1.0, abs(ts)) and abs(dt - hs) <= 1e-7 * hs, (rtol, n, t, dt, ts, hs)
         total += len(accepted)
     assert total >= 12, total
+
+
+def _closed_form_step(f):
+    """A step function with FusedNet.make_step's contract for a closed-form right-hand side, as adaptive.HostSteppedPair
+    uses it: one evaluation row, the derivative back as aux_0."""
+    return lambda y, k1, lp0, kl1, t_rows, cin, slots, tail, use_y, n_aux: (f(t_rows[0], y)[None], None)
+
+
+def test_dopri8_dense_output_does_not_lean_on_the_restated_midpoint():
+    """The dopri8 dense-output MIDPOINT weights are this build's own derivation (torchdiffeq's could not be restated,
+    DESIGN.md section 6), and product and oracle share them -- so two checks that do not:
+    (1) a last step that lands exactly on t_end (x == 1): torchdiffeq evaluates its quartic there too (no shortcut), whose
+        midpoint terms cancel -- the answer must be the step's y1 to a few ulp WHATEVER the midpoint was;
+    (2) t_end strictly inside the last step of a closed-form problem: the answer must sit within the solver tolerance of
+        the closed form (a wrong midpoint would show as an O(dt^4) interpolation error)."""
+    from flowfusion_amd import adaptive
+    rhs = lambda t, y: -(t * y)                                     # y(t) = y0 exp(-t^2 / 2)
+    y0 = torch.tensor([[1.0, -2.5, 0.3]])
+    exact = lambda t: y0.double() * math.exp(-t * t / 2)
+    opts = {"first_step": 0.4, "max_step": 0.4}                     # 0.4 + 0.4 == 0.8 exactly in float64
+    s = adaptive.HostSteppedPair(_closed_form_step(rhs), False, 1e-6, 1e-6, dict(opts), method="dopri8")
+    y_end, _ = s.integrate(0.0, 0.8, y0.clone(), None)
+    assert s.n_accepted == 2
+    ulp = 2.0 ** -23 * float(y0.abs().max())
+    # two 8th-order steps of 0.4 are far below fp32 rounding; what is left is the quartic itself, whose terms (18 y0, 32 y_mid,
+    # ...) are rounded at ~32 |y| ulp -- torchdiffeq's fp32 evaluation loses the same
+    assert float((y_end.double() - exact(0.8)).abs().max()) < 64 * ulp
+    tab = adaptive.WIDE_TABLEAUX["dopri8"]
+    broken = adaptive.EmbeddedTableau(tab.name, tab.order, tab.alpha, tab.beta, tab.c_sol, tab.c_error,
+                                      tuple(0.0 for _ in tab.c_mid))            # a midpoint that is simply y0
+    s2 = adaptive.HostSteppedPair(_closed_form_step(rhs), False, 1e-6, 1e-6, dict(opts), method="dopri8")
+    s2.tab = broken
+    y_broken, _ = s2.integrate(0.0, 0.8, y0.clone(), None)
+    assert float((y_broken - y_end).abs().max()) <= 64 * ulp         # x == 1: the midpoint's 16 - 32 + 16 cancel to rounding
+    # (2) inside the last step: steps of 0.1 up to 1.3, t_end = 1.27 (x = 0.7)
+    s3 = adaptive.HostSteppedPair(_closed_form_step(rhs), False, 1e-6, 1e-6, {"first_step": 0.1, "max_step": 0.1}, method="dopri8")
+    y_in, _ = s3.integrate(0.0, 1.27, y0.clone(), None)
+    assert s3.n_accepted == 13
+    err = float((y_in.double() - exact(1.27)).abs().max())
+    assert err < 2e-6, err
+    # ... and the check has teeth: the broken midpoint misses the same bar by orders of magnitude
+    s4 = adaptive.HostSteppedPair(_closed_form_step(rhs), False, 1e-6, 1e-6, {"first_step": 0.1, "max_step": 0.1}, method="dopri8")
+    s4.tab = broken
+    y_bad, _ = s4.integrate(0.0, 1.27, y0.clone(), None)
+    assert float((y_bad.double() - exact(1.27)).abs().max()) > 100 * max(err, 1e-7)
