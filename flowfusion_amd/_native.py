@@ -193,7 +193,20 @@ def lib() -> ctypes.CDLL:
         raise RuntimeError(
             f"{path} not found: the HIP library is not built. Run `python -m flowfusion_amd.build` "
             "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
-    L = ctypes.CDLL(str(path))
+    _lib = _bind(ctypes.CDLL(str(path)))
+    return _lib
+
+
+def load_library(path) -> ctypes.CDLL:
+    """A library with this ABI other than the product -- the test-only builds of flowfusion_amd/build.py VARIANTS
+    (tests/test_gpu_skew.py) -- bound like the product library, NOT installed as the one the package launches through."""
+    path = Path(path)
+    if not path.exists():
+        raise RuntimeError(f"{path} not found: run `python -m flowfusion_amd.build`")
+    return _bind(ctypes.CDLL(str(path)))
+
+
+def _bind(L: ctypes.CDLL) -> ctypes.CDLL:
     L.ff_version.restype = ctypes.c_char_p
     L.ff_kernel_count.restype = ctypes.c_int
     L.ff_kernel_name.restype = ctypes.c_char_p
@@ -249,7 +262,6 @@ def lib() -> ctypes.CDLL:
     L.ff_adapt_host_transition.restype = ctypes.c_int
     L.ff_adapt_host_transition.argtypes = [ctypes.POINTER(AdaptConfig), ctypes.POINTER(AdaptState), ctypes.c_int32,
                                            ctypes.POINTER(ctypes.c_float)]
-    _lib = L
     return L
 
 

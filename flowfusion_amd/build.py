@@ -128,6 +128,24 @@ else:
                       [(nh, t, 2, 1, 128) for nh in (1, 2, 3, 4) for t in (0, 1, 2)]
 
 
+# ---- test-only libraries (tests/test_gpu_skew.py; csrc/ff_skew.h) -------------------------------------------------------
+# A handful of instantiations compiled with -DFF_DEBUG_SKEW (one wavefront of every workgroup held back where a missing
+# barrier would show) beside the product library, never in it:
+#   skew        HEAD's kernels: the 256-wide cooperative twin (state-only and with tangent columns) and its one-wavefront
+#               kernel, the wide catch-all, one split-precision kernel
+#   skew_unfix  the same twin with round 3's two synchronisation fixes removed again (-DFF_DEBUG_UNFIX): what the test must
+#               see FAIL, or it guards nothing
+_SKEW_TWIN = [(16, 256, 4, 0, t, 2, 8, 0) for t in (0, 1)]
+VARIANTS = {
+    "skew": dict(defines=["-DFF_DEBUG_SKEW=0"], instances=_SKEW_TWIN, wide=[(16, 1024, 32, 16, 0)], split=[(3, 0, 2, 1, 128)]),
+    "skew_unfix": dict(defines=["-DFF_DEBUG_SKEW=0", "-DFF_DEBUG_UNFIX=1"], instances=_SKEW_TWIN, wide=[], split=[]),
+}
+
+
+def variant_lib(name: str) -> Path:
+    return LIBDIR / f"libflowfusion_amd_{name}.so"
+
+
 def _has_four_slot_twin(inst) -> bool:
     """128-wide kernels for states of up to 16 dimensions: a twin with four stage slots (two workgroups per CU, +26 % on the
     opt-in arithmetic at notebook widths).  Built with FF_BUILD_FULL only since round 3 (12 translation units of a frozen,
@@ -190,7 +208,12 @@ def _write(path: Path, text: str) -> Path:
     return path
 
 
-def _gen_sources() -> list[Path]:
+def _gen_sources(gen: Path | None = None, instances=None, wide=None, split=None) -> list[Path]:
+    """The translation units of a library: the product's (default arguments) or a test variant's instance lists."""
+    GEN = gen if gen is not None else globals()["GEN"]
+    INSTANCES = instances if instances is not None else globals()["INSTANCES"]
+    WIDE_INSTANCES = wide if wide is not None else globals()["WIDE_INSTANCES"]
+    SPLIT_INSTANCES = split if split is not None else globals()["SPLIT_INSTANCES"]
     GEN.mkdir(parents=True, exist_ok=True)
     files = []
     tf = lambda t: "true" if t else "false"
@@ -231,10 +254,13 @@ def _gen_sources() -> list[Path]:
         for i in INSTANCES
     )
     # wide catch-alls: no one-wavefront kernel (launch = nullptr), the cooperative launcher serves every batch size
-    rows += ",\n" + ",\n".join(
-        f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, 0, nullptr, "{_wide_name(*i)}", launch_{_wide_name(*i)}, 0}}'
-        for i in WIDE_INSTANCES
-    )
+    if WIDE_INSTANCES:
+        rows += ",\n" + ",\n".join(
+            f'    {{{i[0]}, {i[1]}, {i[2]}, {i[3]}, {i[4]}, 0, nullptr, "{_wide_name(*i)}", launch_{_wide_name(*i)}, 0}}'
+            for i in WIDE_INSTANCES
+        )
+    if not SPLIT_INSTANCES:          # (a test variant without the family: one inert row, count 0 -- no zero-length array)
+        split_rows = '    {0, 0, 0, 0, 0, nullptr, "", nullptr}'
     table = f"""// generated by flowfusion_amd/build.py -- do not edit
 #include "ff_registry.h"
 namespace ff {{
@@ -305,8 +331,9 @@ def _deps_hash(src: Path) -> str:
     return h.hexdigest()
 
 
-def _compile(src: Path, dep_hash: str, verbose: bool) -> Path:
-    key = hashlib.sha256(dep_hash.encode() + src.read_bytes() + src.name.encode()).hexdigest()[:16]
+def _compile(src: Path, dep_hash: str, verbose: bool, obj_dir: Path | None = None, defines=()) -> Path:
+    OBJ = obj_dir if obj_dir is not None else globals()["OBJ"]
+    key = hashlib.sha256(dep_hash.encode() + src.read_bytes() + src.name.encode() + " ".join(defines).encode()).hexdigest()[:16]
     obj = OBJ / f"{src.stem}.{key}.o"
     if obj.exists():
         return obj
@@ -316,7 +343,7 @@ def _compile(src: Path, dep_hash: str, verbose: bool) -> Path:
         lang = ["-x", "hip", f"--offload-arch={ARCH}"]
     else:                       # host-only C++ (C ABI, packer, kernel table)
         lang = ["-x", "c++", "-D__HIP_PLATFORM_AMD__=1", f"-I{Path(_hipcc()).resolve().parents[1] / 'include'}"]
-    cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", *lang,
+    cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-Wno-inline-asm", *lang, *defines,
            f"-I{CSRC}", f"-I{ROOT / 'include'}", "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -326,28 +353,44 @@ def _compile(src: Path, dep_hash: str, verbose: bool) -> Path:
     return obj
 
 
-def build(verbose: bool = False, jobs: int | None = None) -> Path:
-    """Compile every kernel instantiation for gfx950 and link the shared library."""
-    OBJ.mkdir(parents=True, exist_ok=True)
-    LIBDIR.mkdir(parents=True, exist_ok=True)
-    srcs = _gen_sources()
-    jobs = jobs or min(8, os.cpu_count() or 1)
-    # longest first (estimated), so that no slow translation unit trails the pool
-    order = sorted(srcs, key=lambda s: (-_cost(s), s.name))
-    with ThreadPoolExecutor(max_workers=jobs) as ex:
-        done = dict(zip(order, ex.map(lambda s: _compile(s, _deps_hash(s), verbose), order)))
-    objs = [done[s] for s in srcs]
+def _link(objs, lib: Path, stamp_file: Path, verbose: bool) -> Path:
     stamp = hashlib.sha256("".join(sorted(o.name for o in objs)).encode()).hexdigest()
-    stamp_file = PKG / "_build" / ("link_full.stamp" if FULL else "link.stamp")
-    if LIB.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
-        return LIB
-    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]
+    if lib.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
+        return lib
+    cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib)] + [str(o) for o in objs]
     if verbose:
         print(" ".join(cmd[:6]), "...", flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     stamp_file.write_text(stamp)
+    return lib
+
+
+def build(verbose: bool = False, jobs: int | None = None, variants: bool = True) -> Path:
+    """Compile every kernel instantiation for gfx950 and link the shared library -- and, beside it, the small test-only
+    libraries of VARIANTS (``variants=False`` skips them).  All translation units share one pool, longest first."""
+    OBJ.mkdir(parents=True, exist_ok=True)
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    srcs = _gen_sources()
+    units = [(s, OBJ, ()) for s in srcs]
+    extra = {}
+    if variants and not FULL:
+        for name, v in VARIANTS.items():
+            gen, obj = PKG / "_build" / f"gen_{name}", PKG / "_build" / f"obj_{name}"
+            obj.mkdir(parents=True, exist_ok=True)
+            vs = _gen_sources(gen, v["instances"], v["wide"], v["split"])
+            extra[name] = (vs, obj, tuple(v["defines"]))
+            units += [(s, obj, tuple(v["defines"])) for s in vs]
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    # longest first (estimated), so that no slow translation unit trails the pool
+    order = sorted(units, key=lambda u: (-_cost(u[0]), u[0].name, str(u[1])))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        done = dict(zip([(u[0], u[1]) for u in order],
+                        ex.map(lambda u: _compile(u[0], _deps_hash(u[0]), verbose, u[1], u[2]), order)))
+    _link([done[(s, OBJ)] for s in srcs], LIB, PKG / "_build" / ("link_full.stamp" if FULL else "link.stamp"), verbose)
+    for name, (vs, obj, _) in extra.items():
+        _link([done[(s, obj)] for s in vs], variant_lib(name), PKG / "_build" / f"link_{name}.stamp", verbose)
     return LIB
 
 

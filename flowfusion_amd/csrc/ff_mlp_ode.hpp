@@ -25,6 +25,8 @@
 #include "ff_kernel_args.h"
 #include "ff_philox.h"
 
+#include "ff_skew.h"
+
 namespace ff {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -543,10 +545,12 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     // (cooperative twin: one copy -- the four wavefronts hold the same tile and write the same values)
     f32x4* const ks = lds_slots + (size_t)(COOP ? 0 : (threadIdx.x >> 6)) * kSlots * R4 * 64 + lane;
     f32x4* const exch = lds_slots + (size_t)kSlots * R4 * 64 + lane;         // COOP: 2 (WIDE: 1) x (KH / 4) x 64 exchange slots
+    FF_SKEW_HOLD(COOP && wv == kSkewWave, 1);          // (test builds: this wavefront starts late ...)
 #pragma unroll
     for (int s = 0; s < kSlots; ++s)
 #pragma unroll
         for (int j = 0; j < R4; ++j) ks[(s * R4 + j) * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
+    FF_SKEW_HOLD(COOP && wv == kSkewWave, 2);          // (... and lingers between its zero fill and its first store)
     float kl[kSlots];
 #pragma unroll
     for (int s = 0; s < kSlots; ++s) kl[s] = 0.f;
@@ -554,7 +558,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     // Cooperative twin: the four wavefronts share the slots.  Everything they store there later is the same value from
     // each of them, so late or repeated stores are harmless -- except this zero fill: a wavefront that starts late would
     // wipe the caller's first stage (below) between another wavefront's store and its first read.  All fills first.
+#if !defined(FF_DEBUG_UNFIX)
     if constexpr (COOP) __syncthreads();
+#endif
     if (args.k1_in) {            // first stage supplied by the caller (FSAL of the previous step)
 #pragma unroll
         for (int j = 0; j < R4; ++j) {
@@ -567,6 +573,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
             ks[j * 64] = v;
         }
     }
+    FF_SKEW_HOLD(COOP && wv != kSkewWave, 2);          // (test builds: the others wait between that store and their first read)
     if constexpr (TANGENTS) {
         // the per-sample divergence of stage 0 is carried by ONE lane of the sample (first tangent
         // column, lane group 0); all other lanes integrate their own partial sums from zero
@@ -622,6 +629,9 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
     // the same buffer, with a single barrier between a slow wavefront's reads of the old contents and a fast one's stores.
     [[maybe_unused]] int xbuf = 0;
     for (int e = 0; e < args.n_evals; ++e) {
+#if defined(FF_DEBUG_UNFIX)
+        xbuf = 0;                  // (round 3's second hole, restored for the test: the count restarts with every evaluation)
+#endif
         const int row_byte = e * args.etab_stride * 4;
         HdrPtr hdr = (HdrPtr)(args.etab + (size_t)e * args.etab_stride);
         const float a_e = hdr->a, b_e = hdr->b;
@@ -735,6 +745,7 @@ __global__ __launch_bounds__(256, WPS) void mlp_ode_kernel(const KernelArgs args
                     });
                 });
                 __syncthreads();
+                FF_SKEW_HOLD(wv == kSkewWave, 2);       // (test builds: late to read what the others are about to overwrite)
                 if constexpr (!WIDE) {
 #pragma unroll
                     for (int k4 = 0; k4 < KH / 4; ++k4) {

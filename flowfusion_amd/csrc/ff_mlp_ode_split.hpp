@@ -48,6 +48,7 @@
 #include "ff_kernel_args.h"
 #include "ff_split_layout.h"
 #include "ff_philox.h"
+#include "ff_skew.h"
 
 namespace ff {
 namespace split {
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
         dma_fragment(M.c1 + (e & 1) * 1024, (const unsigned char*)(args.etab + (size_t)ee_ * args.etab_stride + 32),
                      lane16 < H * 4 - 16 ? lane16 : H * 4 - 16);
     };
+    FF_SKEW_HOLD(wv == kSkewWave, 1);                  // (test builds, ff_skew.h: this wavefront starts late ...)
     fetch_c1(0);
     for (int g = 0; g < NBUF - 1; ++g) {               // the first NBUF - 1 granules into their buffers
 #pragma unroll
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(256, (NSL == 4 && has_four_slot_twin(NP, DT, HW)) ?
 #ifndef FF_SPLIT_NOBARRIER       // timing experiment only (with FF_SPLIT_NODMA)
             __builtin_amdgcn_s_barrier();
 #endif
+            FF_SKEW_HOLD(wv == kSkewWave, 1);          // (... and is late behind every granule barrier)
             rbuf += GB;
             if (rbuf >= NBUF * GB) rbuf = 0;
             wa_next = lane16 + rbuf;
