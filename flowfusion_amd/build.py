@@ -142,6 +142,14 @@ VARIANTS = {
 }
 
 
+if os.environ.get("FF_BUILD_NOSLP", "") not in ("", "0"):
+    # one-off A/B (round 4; scratch/slp_ab.py): the headline, config-3 and notebook kernels with hipcc's SLP
+    # vectoriser off -- it packs the SiLU tail's scalar products into v_pk_mul_f32 / v_pk_fma_f32 between the MFMAs
+    VARIANTS["noslp"] = dict(defines=["-fno-slp-vectorize"],
+                             instances=[(16, 256, 4, 0, 0, 2, 8, 0), (16, 256, 4, 0, 1, 2, 8, 0), (16, 128, 4, 0, 0, 3, 4, 0),
+                                        (16, 128, 4, 0, 1, 3, 4, 0)], wide=[], split=[])
+
+
 def variant_lib(name: str) -> Path:
     return LIBDIR / f"libflowfusion_amd_{name}.so"
 

@@ -295,7 +295,12 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
     }
     return;
 #endif
-    // scalar code on purpose: packed f32 VALU (v_pk_*) issued beside MFMAs costs more than it saves
+    // Written as scalar code; what the compiler makes of it is its own business: hipcc's SLP vectoriser packs part of this
+    // tail into v_pk_mul_f32 / v_pk_fma_f32 (headline kernel: 138 packed instructions, 38 of them between MFMAs; with
+    // -fno-slp-vectorize 92 remain -- the f32x4 stage algebra -- and 2 between MFMAs).  Measured both ways in round 4
+    // (scratch/slp_ab.py, profiles/r04/slp_ab.txt): headline 1224.0 vs 1226.5 ms, config 3 2521.4 vs 2520.8 ms, the
+    // 128-wide notebook kernels 59.88 vs 59.97 and 199.31 vs 199.33 ms, bitwise the same results -- packing neither costs
+    // nor saves here, so the build keeps the compiler's default.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if constexpr (STAGE == 0) {
