@@ -4,17 +4,33 @@
 // The reference evaluates the two estimators inside ScoreModel.forward (flowfusion/diffusion.py:336-481), i.e. once per
 // right-hand-side evaluation of the solver, through 2r + m reverse-mode products and a batched `torch.linalg.qr`.  On the
 // fused path a launch in FF_MODE_EXACT with ff_ode_args.jac_all = 1 leaves A = J^T of EVERY evaluation row in memory
-// ([n_rows][batch][D][D]); this kernel turns them into the estimates [n_rows][batch] in one pass, so that an attempted
-// step of the adaptive solver stays on the device (ff_adaptive.hip) and a fixed-grid solve needs no torch linear algebra.
+// ([n_rows][batch][D][D]); this file turns them into the estimates [n_rows][batch] in one pass, so that an attempted step of
+// the adaptive solver stays on the device (ff_adaptive.hip) and a fixed-grid solve needs no torch linear algebra.
 //
-// Roofline: HBM.  A work item reads its D x D matrix (three times at most; the second and third pass hit L2) and keeps
-// its D x r factor in a workspace laid out item-fastest, so consecutive lanes touch consecutive words.
+// Roofline: HBM -- algorithmically one read of the Jacobians (4 D^2 bytes per work item) and 4 bytes written.
+//
+//   trace_estimate_tile_kernel<DC>   the fast path (D <= 16, and the tile fits LDS): one wavefront = 64 consecutive work
+//       items.  Their matrices are one contiguous stretch of memory: the wavefront streams it with coalesced loads (lane l
+//       takes element l of every 64) and scatters it into LDS TRANSPOSED to item-fastest with an odd pitch (65 words), so
+//       that both the scatter (consecutive elements of one matrix -> consecutive banks) and every later read (lane = item ->
+//       consecutive banks) are conflict-free.  The factorisation's scratch lives in LDS the same way.  Then each lane runs its
+//       item's estimator (ff_trace_est.h) out of LDS with the dimension fixed at compile time: the operand vector of every
+//       product sits in registers, the dot products unroll and their LDS reads are issued in batches instead of one
+//       dependent load at a time.
+//   trace_estimate_kernel            the general path (any D, r, m): one thread per item straight from global memory, scratch
+//       in a caller-provided workspace laid out item-fastest.  Latency-bound (dependent uncoalesced loads); correct for
+//       shapes the tile path does not hold.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 #include "flowfusion_amd.h"
+#include "ff_registry.h"
 #include "ff_trace_est.h"
 
 namespace ff {
+
+constexpr int kTilePitch = 65;          // words between consecutive LDS rows of a 64-item tile (odd: conflict-free both ways)
 
 __global__ __launch_bounds__(256) void trace_estimate_kernel(const ff_trace_args a, long long items)
 {
@@ -24,13 +40,109 @@ __global__ __launch_bounds__(256) void trace_estimate_kernel(const ff_trace_args
     const long long b = t % a.batch;
     trace::Item it;
     it.A = a.jac + (size_t)t * a.dim * a.dim;
+    it.astride = 1;
     it.p0 = a.probes0 + (size_t)b * a.dim;
+    it.pstride0 = (size_t)a.batch * a.dim; it.pk0 = 1;
     it.p1 = a.probes1 ? a.probes1 + (size_t)b * a.dim : nullptr;
-    it.pstride = (size_t)a.batch * a.dim;
+    it.pstride1 = (size_t)a.batch * a.dim; it.pk1 = 1;
     it.ws = a.workspace + t;
     it.stride = (size_t)items;
     it.D = a.dim; it.r = a.r; it.m = a.m;
-    a.out[t] = trace::estimate(a.kind, it);
+    a.out[t] = trace::estimate<0>(a.kind, it);
+}
+
+// LDS words of a 64-item tile: matrices and scratch (the probes are read from global memory: with the operand vectors of
+// the products held in registers every probe entry is read once or twice)
+__host__ __device__ inline size_t tile_lds_words(int kind, int D, int r)
+{
+    return (size_t)kTilePitch * ((size_t)D * D + trace::workspace_per_item(kind, D, r));
+}
+
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+template <int DC>
+__global__ __launch_bounds__(64) void trace_estimate_tile_kernel(const ff_trace_args a, long long items)
+{
+    if (a.gate && *(const volatile int32_t*)a.gate == 0) return;
+    extern __shared__ float tile[];
+    const int D = DC ? DC : a.dim, DD = D * D;
+    const int lane = threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * 64;
+    const int n_here = (int)(items - t0 < 64 ? items - t0 : 64);
+    float* const a_lds = tile;                                   // [D * D][pitch]
+    float* const w_lds = a_lds + (size_t)DD * kTilePitch;        // [workspace_per_item][pitch]
+
+    // the tile's matrices: n_here * D * D contiguous floats; element e = item * DD + idx -> a_lds[idx * pitch + item].
+    // Sixteen 16-byte loads per lane in flight (16 KiB per wavefront) when the stretch is 16-byte aligned, else eight dwords.
+    const float* src = a.jac + (size_t)t0 * DD;
+    const int n_el = n_here * DD;
+    if ((DD & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+        const int n4 = n_el >> 2;
+        for (int e0 = 0; e0 < n4; e0 += 64 * 16) {
+            f32x4g v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u * 64 + lane;
+                v[u] = e < n4 ? ((const f32x4g*)src)[e] : f32x4g{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = (e0 + u * 64 + lane) * 4;
+                if (e < n_el) {
+                    const int item = e / DD, idx = e - item * DD;          // (DD % 4 == 0: the four words share an item)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a_lds[(idx + q) * kTilePitch + item] = v[u][q];
+                }
+            }
+        }
+    } else {
+        for (int e0 = 0; e0 < n_el; e0 += 64 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64 + lane;
+                v[u] = e < n_el ? src[e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 64 + lane;
+                if (e < n_el) {
+                    const int item = e / DD, idx = e - item * DD;
+                    a_lds[idx * kTilePitch + item] = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lane >= n_here) return;
+    const long long t = t0 + lane, b = t % a.batch;
+    trace::Item it;
+    it.A = a_lds + lane; it.astride = kTilePitch;
+    it.p0 = a.probes0 + (size_t)b * D;
+    it.pstride0 = (size_t)a.batch * D; it.pk0 = 1;
+    it.p1 = a.probes1 ? a.probes1 + (size_t)b * D : nullptr;
+    it.pstride1 = (size_t)a.batch * D; it.pk1 = 1;
+    it.ws = w_lds + lane; it.stride = kTilePitch;
+    it.D = D; it.r = a.r; it.m = a.m;
+    a.out[t] = trace::estimate<DC>(a.kind, it);
+}
+
+template <int DC>
+static hipError_t launch_tile(const ff_trace_args* a, long long items, size_t lds_bytes, hipStream_t s)
+{
+    auto kern = trace_estimate_tile_kernel<DC>;
+    // the dynamic-LDS limit is a per-device attribute of the function: set it once per device of this process
+    static std::atomic<unsigned char> ready[kMaxDevices];
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return err;
+    if (dev < 0 || dev >= kMaxDevices || !ready[dev].load(std::memory_order_acquire)) {
+        err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return err;
+        if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 63) / 64)), dim3(64), lds_bytes, s, *a, items);
+    return hipGetLastError();
 }
 
 } // namespace ff
@@ -56,9 +168,27 @@ extern "C" int ff_trace_estimate(const ff_trace_args* a, void* hip_stream)
     if (rc != FF_OK) return rc;
     const long long items = (long long)a->n_rows * a->batch;
     if (items == 0) return FF_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    // the tile path: D <= 16 and a 64-item tile (matrices + scratch) within a CU's LDS (up to 80 KB two tiles
+    // share a CU and one loads while the other computes).  FF_TRACE_GENERIC=1 pins the general kernel (A/B runs, tests).
+    const size_t lds_bytes = 4 * ff::tile_lds_words(a->kind, a->dim, a->r);
+    const char* pin = getenv("FF_TRACE_GENERIC");
+    if (a->dim <= 16 && lds_bytes <= 156 * 1024 && !(pin && atoi(pin) != 0) && (items + 63) / 64 <= 0x7fffffffll) {
+        hipError_t err;
+        switch (a->dim) {
+        case 1: err = ff::launch_tile<1>(a, items, lds_bytes, s); break;
+        case 2: err = ff::launch_tile<2>(a, items, lds_bytes, s); break;
+        case 3: err = ff::launch_tile<3>(a, items, lds_bytes, s); break;
+        case 4: err = ff::launch_tile<4>(a, items, lds_bytes, s); break;
+        case 8: err = ff::launch_tile<8>(a, items, lds_bytes, s); break;
+        case 16: err = ff::launch_tile<16>(a, items, lds_bytes, s); break;
+        default: err = ff::launch_tile<0>(a, items, lds_bytes, s); break;        // run-time dimension, same layout
+        }
+        return err == hipSuccess ? FF_OK : FF_ERR_HIP;
+    }
     const long long grid = (items + 255) / 256;
     if (grid > 0x7fffffffll) return FF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ff::trace_estimate_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)hip_stream, *a, items);
+    hipLaunchKernelGGL(ff::trace_estimate_kernel, dim3((unsigned)grid), dim3(256), 0, s, *a, items);
     return hipGetLastError() == hipSuccess ? FF_OK : FF_ERR_HIP;
 }
 
@@ -72,13 +202,15 @@ extern "C" int ff_trace_estimate_host(const ff_trace_args* a)
         const long long b = t % a->batch;
         ff::trace::Item it;
         it.A = a->jac + (size_t)t * a->dim * a->dim;
+        it.astride = 1;
         it.p0 = a->probes0 + (size_t)b * a->dim;
+        it.pstride0 = (size_t)a->batch * a->dim; it.pk0 = 1;
         it.p1 = a->probes1 ? a->probes1 + (size_t)b * a->dim : nullptr;
-        it.pstride = (size_t)a->batch * a->dim;
+        it.pstride1 = (size_t)a->batch * a->dim; it.pk1 = 1;
         it.ws = a->workspace;
         it.stride = 1;
         it.D = a->dim; it.r = a->r; it.m = a->m;
-        a->out[t] = ff::trace::estimate(a->kind, it);
+        a->out[t] = ff::trace::estimate<0>(a->kind, it);
     }
     return FF_OK;
 }

@@ -28,11 +28,18 @@ def _need_gpu(built_library):
     assert torch.cuda.is_available(), "the gpu tier needs a GPU"
 
 
-def test_trace_estimate_kernel_against_the_torch_statement():
+@pytest.mark.parametrize("generic", [False, True])
+def test_trace_estimate_kernel_against_the_torch_statement(generic, monkeypatch):
+    """Both device kernels of ff_trace.hip -- the LDS-tile path (D <= 16 and the tile fits; compile-time dimensions 1, 2, 3,
+    4, 8, 16 and the run-time-dimension instantiation) and the general path (pinned with FF_TRACE_GENERIC=1; what larger
+    shapes take anyway) -- over ragged tiles (batches that are no multiple of 64, tiles spanning two evaluation rows)."""
     from flowfusion_amd import _native, trace_estimators as TE
+    if generic:
+        monkeypatch.setenv("FF_TRACE_GENERIC", "1")
     torch.manual_seed(23)
     for D, r, m, B, n in ((2, 1, 1, 1000, 6), (16, 1, 1, 300, 6), (5, 2, 3, 77, 2), (32, 3, 2, 65, 1), (16, 16, 1, 40, 3),
-                          (3, 2, 7, 513, 2), (1, 1, 2, 5, 1), (64, 4, 4, 9, 2)):
+                          (3, 2, 7, 513, 2), (1, 1, 2, 5, 1), (64, 4, 4, 9, 2), (8, 3, 2, 100, 3), (4, 4, 1, 129, 2),
+                          (16, 4, 4, 70, 2), (12, 2, 2, 33, 5)):
         A = torch.randn(n, B, D, D)
         S, G = torch.sign(torch.randn(r, B, D)), torch.sign(torch.randn(m, B, D))
         rep = lambda P: P.unsqueeze(1).expand(P.shape[0], n, B, D).reshape(P.shape[0], n * B, D).double()
