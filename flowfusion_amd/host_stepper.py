@@ -1,12 +1,14 @@
-"""Row-by-row execution of an evaluation table, for divergence estimators that need the whole Jacobian of
-every right-hand-side evaluation (Hutch++, XTrace).
+"""Hutch++ / XTrace solves outside the device-resident adaptive path (device_adaptive.py, which is where the reference's
+default-argument calls run since round 4).
 
-The fused kernel normally runs a whole table in one launch.  The two estimators factorise a sketch of the
-Jacobian per sample and evaluation (a QR), which the kernel does not do; so here each row becomes one launch
-(``flowfusion_amd::mlp_rhs_jac``: the right-hand side and its full Jacobian from unit tangents, the network
-still fused), the estimate is a few batched torch operations on the device (trace_estimators.py), and the
-Runge-Kutta bookkeeping -- the same ``cin`` / ``cout`` / slot semantics the kernel implements -- is done on
-the host.  The same interpreter serves the adaptive driver as a step function.
+* ``run_table_recorded``: FIXED grids -- the state never depends on the divergence, so the whole table runs as one fused
+  launch per tangent pass with the Jacobian of every row recorded (``ff_ode_args.jac_all``), ONE ``ff_trace_estimate``
+  launch turns them into estimates, and the rows are combined with the tableau's weights.
+* ``rhs_div`` / ``make_step`` / ``run_table``: row-by-row execution -- each right-hand side one launch
+  (``flowfusion_amd::mlp_rhs_jac``: the value and its full Jacobian from unit tangents, the network still fused), the
+  estimate by ``div_fn``, the Runge-Kutta bookkeeping (the kernel's ``cin`` / ``cout`` / slot semantics) on the host.  This
+  is the HOST-controller route of an adaptive estimator solve (``FF_HOST_CONTROLLER=1``, SDE classes the device controller
+  does not know, Jacobians beyond the memory budget) and what the CPU tests drive with the kernel-semantics emulator.
 """
 from __future__ import annotations
 

@@ -9,6 +9,11 @@ so that given the same probes both give the same estimate up to fp32 rounding.
 
 All functions take ``A`` of shape [B, D, D] and probe tensors laid out like the reference's
 (``[n_probes, B, D]``, entries +-1), and return the divergence estimate [B].
+
+Since round 4 the fused path evaluates the estimators in its own kernel (csrc/ff_trace_est.h / ff_trace.hip: the same
+formulas, one launch for every evaluation row); this module stays as the torch statement of them -- pinned by the
+reference's fixtures in the CPU tier, the comparator of the kernel in both tiers, what ``ScoreModel.forward`` uses on CPU
+tensors, and (``FF_TORCH_ESTIMATOR=1``) rounds 1-3's route for A/B runs.
 """
 from __future__ import annotations
 
