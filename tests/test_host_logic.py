@@ -104,6 +104,19 @@ def test_no_cpu_fallback(built_library):
         f.sample(torch.randn(4, 3))                              # adaptive dopri5 default, as in the reference
     with pytest.raises(RuntimeError, match="GPU"):
         f.sample(torch.randn(4, 3), method="rk4", options={"step_size": 0.1})
+    # the estimator solves: GPU only as well (adaptive default and fixed grid), and the flows' probe arguments are checked
+    # before anything is launched
+    hpp = D.ScoreModel(D.MLP(4, 0, 8, [64, 64]), D.VPSDE(), no_sigma=True, hutchpp=True).eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        hpp.log_prob(torch.randn(8, 4))
+    with pytest.raises(RuntimeError, match="GPU"):
+        hpp.log_prob(torch.randn(8, 4), method="rk4", options={"step_size": 0.25})
+    with pytest.raises(ValueError, match="'torch' or 'philox'"):
+        f.log_prob(torch.randn(4, 3), hutchinson=True, probe="sobol")
+    with pytest.raises(ValueError, match="hutchinson=True"):
+        f.log_prob(torch.randn(4, 3), probe="philox")
+    with pytest.raises(ValueError, match="seed="):
+        f.log_prob(torch.randn(4, 3), hutchinson=True, seed=3)
 
 
 # ---- solvers -------------------------------------------------------------------------------------
@@ -669,3 +682,34 @@ def test_other_dtypes_are_refused_not_rounded(built_library):
     f = Fm.ODEFlow(3, [64, 64]).eval().double()
     with pytest.raises(TypeError, match="float32"):
         f.sample(torch.randn(4, 3))
+
+
+def test_launch_kind_states_the_launchers_rule(built_library, monkeypatch):
+    """ff_mlp_launch_kind (no GPU needed): the launcher's choice between the one-wavefront kernel, its cooperative twin and
+    both, as a query -- what the GPU tests assert instead of a wall-clock ratio.  Config 2's network: 16 samples per tile,
+    two wavefronts per SIMD, 2,048 tiles in flight."""
+    from flowfusion_amd import _native
+    monkeypatch.delenv("FF_COOP", raising=False)
+    monkeypatch.delenv("FF_TAIL_SPLIT", raising=False)
+    p0 = _native.make_plan(16, 0, [256] * 4, 0)
+    kinds = {b: _native.launch_kind(p0, b, 0) for b in (1, 2048, 12288, 16384, 32768, 32768 + 300, 1 << 20)}
+    T, W, B = _native.LAUNCH_TWIN, _native.LAUNCH_ONE_WAVE, _native.LAUNCH_ONE_WAVE_AND_TWIN
+    assert kinds == {1: T, 2048: T, 12288: T, 16384: W, 32768: W, 32768 + 300: B, 1 << 20: W}
+    assert _native.launch_kind(p0, 32768 + 300, 0, jac_out=True) == W              # a Jacobian output is never split
+    monkeypatch.setenv("FF_TAIL_SPLIT", "0")
+    assert _native.launch_kind(p0, 32768 + 300, 0) == W
+    monkeypatch.setenv("FF_COOP", "0")
+    assert _native.launch_kind(p0, 2048, 0) == W
+    monkeypatch.setenv("FF_COOP", "1")
+    assert _native.launch_kind(p0, 1 << 20, 0) == T
+    monkeypatch.delenv("FF_COOP")
+    # tangent columns change the samples per tile (Hutchinson: 8; exact trace with 15 tangents: 1)
+    p1 = _native.make_plan(16, 0, [256] * 4, 1)
+    assert _native.launch_kind(p1, 8 * 700, 1) == T and _native.launch_kind(p1, 8 * 4096, 1) == W
+    p2 = _native.make_plan(16, 0, [256] * 4, 2)
+    assert _native.launch_kind(p2, 700, 2, tangent_count=15) == T
+    # the wide catch-all is cooperative at every size
+    pw = _native.make_plan(100, 40, [700, 700], 0)
+    assert _native.launch_kind(pw, 1 << 18, 0) == T
+    with pytest.raises(RuntimeError, match="FF_ERR_BADARG"):
+        _native.launch_kind(p0, -1, 0)
