@@ -726,8 +726,10 @@ class ScoreModel(nn.Module):
             # fixed grid: one launch per tangent pass records every row's Jacobian, one launch estimates all of them
             stepper = host_stepper.RowStepper(net, x.device, conditional, None)
             div_rows = lambda A, lo, hi: _native.trace_estimate(A, kind, tuple(P[:, lo:hi] for P in probes))
+            # (the recorded Jacobians of a chunk of samples may take a quarter of the free device memory: cutting a batch
+            # into many small launches leaves their last rounds of tiles mostly empty)
             y, lp = stepper.run_table_recorded(x, self._ode_table(t_span, method, options, MODE_EXACT), div_rows,
-                                               cond=conditional)
+                                               cond=conditional, max_bytes=max(1 << 30, self._estimator_budget(x.device) // 2))
         return y, lp.view(-1, 1)
 
     @staticmethod
