@@ -150,6 +150,10 @@ if os.environ.get("FF_BUILD_NOSLP", "") not in ("", "0"):
                                         (16, 128, 4, 0, 1, 3, 4, 0)], wide=[], split=[])
 
 
+if os.environ.get("FF_BUILD_EXP_DPP", "") not in ("", "0"):
+    VARIANTS["dpp"] = dict(defines=["-DFF_EXP_DPP=1"], instances=[(16, 256, 4, 0, 1, 2, 8, 0), (16, 128, 4, 0, 1, 3, 4, 0)], wide=[], split=[])
+
+
 def variant_lib(name: str) -> Path:
     return LIBDIR / f"libflowfusion_amd_{name}.so"
 

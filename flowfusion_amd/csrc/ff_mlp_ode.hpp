@@ -314,7 +314,11 @@ __device__ __forceinline__ void act_stage(ActGroup& g, float* __restrict__ dst, 
                 // silu'(a) = s + a s (1 - s) = s (1 + a (1 - s)),  s = sigmoid(a): two fmas
                 const float w = __builtin_fmaf(-g.pre[i], g.r[i], g.pre[i]);
                 const float d = __builtin_fmaf(g.r[i], w, g.r[i]);
+#ifdef FF_EXP_DPP       // timing experiment only (Hutchinson pairs: the value column is the lane to the left)
+                g.dv[i] = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x111, 0xf, 0xf, false);
+#else
                 g.dv[i] = __builtin_amdgcn_ds_bpermute(value_lane_bytes, __builtin_bit_cast(int, d));
+#endif
             } else {
                 dst[i] = g.pre[i] * g.r[i];
             }
