@@ -17,7 +17,7 @@ static_assert(sizeof(ff_adapt_state) == 128, "controller state is 128 bytes");
 
 static thread_local int t_last_hip_error = 0;
 
-extern "C" const char* ff_version(void) { return "flowfusion_amd 0.3 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 / bf16x2 split on 16x16x32 bf16; in-register layer chaining; device-side adaptive step control)"; }
+extern "C" const char* ff_version(void) { return "flowfusion_amd 0.4 gfx950 (f32 MFMA 16x16x4 / 32x32x2, opt-in bf16x3 / bf16x2 split on 16x16x32 bf16; in-register layer chaining; device-side adaptive step control; Hutch++ / XTrace estimator kernels)"; }
 
 extern "C" int ff_kernel_count(void) { return ff::g_n_kernels + ff::g_n_split_kernels; }
 
