@@ -623,6 +623,22 @@ def streaming_helpers(device):
         ms_of(lambda: _native.scaled_rms([(ks[1], None, x, ks[0])], 1e-5, 1e-5, check=ks[0], read=False)))
     rec("ff_normal_fill (4 B per element written; Philox4x32-10 + Box-Muller)", 4 * n,
         ms_of(lambda: _native.normal_fill(B, D, 1234, 0, device)))
+    # the Hutch++ / XTrace estimator launch of an adaptive attempt at solver size: 6 evaluation rows x 2^16 samples of 16 x 16
+    # Jacobians (one read of them is the algorithmic traffic), one sketch probe and one residual probe as in the reference's
+    # defaults; the LDS-tile kernel (D <= 16) and, for the record, the general one-thread-per-item kernel
+    Bj = 1 << 16
+    jac = torch.randn(6, Bj, D, D, device=device)
+    S, G = (torch.sign(torch.randn(1, Bj, D, device=device)) for _ in range(2))
+    nbytes = jac.numel() * 4 + 4 * 6 * Bj
+    rec("ff_trace_estimate, Hutch++ r = m = 1 on 6 x 2^16 Jacobians of 16 x 16 (1 KiB read per work item; LDS-tile kernel)", nbytes,
+        ms_of(lambda: _native.trace_estimate(jac, "hutchpp", (S, G))))
+    rec("ff_trace_estimate, XTrace m = 1, same Jacobians", nbytes, ms_of(lambda: _native.trace_estimate(jac, "xtrace", (S,))))
+    os.environ["FF_TRACE_GENERIC"] = "1"
+    try:
+        rec("ff_trace_estimate, Hutch++ r = m = 1, general kernel (FF_TRACE_GENERIC=1: what shapes beyond the tile path take)", nbytes,
+            ms_of(lambda: _native.trace_estimate(jac, "hutchpp", (S, G)), reps=3))
+    finally:
+        os.environ.pop("FF_TRACE_GENERIC", None)
     return rows
 
 

@@ -154,3 +154,36 @@ def test_estimator_solves_on_other_pairs_and_first_step(monkeypatch):
         (ld, sd), (lh, sh) = _both_routes(monkeypatch, run)
         assert (sd["attempts"], sd["accepted"]) == (sh["attempts"], sh["accepted"]), (kwargs, sd, sh)
         assert _logp_err(ld, lh.cpu()) < 5e-5, kwargs
+
+
+def test_estimator_solves_at_size_properties(monkeypatch):
+    """Size-independent properties of an estimator solve at 2^16 x 16-d (config 2's network): flipping the sign of every
+    probe leaves Hutch++ and XTrace unchanged BIT FOR BIT (q -> -q, u -> -u: every product keeps its value), a repeated run
+    is bitwise equal, and on a fixed grid a slice of the batch solved on its own returns the rows of the whole solve."""
+    from flowfusion_amd import trace_estimators as TE
+    sm, _, _ = _seeded_score_model(16, 0, [256] * 4, "VPSDE", True, 12)
+    B = 1 << 16
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, 16, device=DEV, generator=g) * 0.8
+    S, G, O = (torch.sign(torch.randn(n, B, 16, device=DEV, generator=g)) for n in (1, 2, 2))
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 5}
+    for kind, probes in (("hutchpp", [S, G]), ("xtrace", [O])):
+        sm.hutchpp, sm.xtrace, sm.hpp_rank, sm.hpp_vector, sm.xt_vector = kind == "hutchpp", kind == "xtrace", 1, 2, 2
+
+        def run(sign, rows=slice(None), **kw):
+            queue = [sign * p[:, rows].contiguous() for p in probes]
+            monkeypatch.setattr(TE, "draw_probes", lambda n, like: queue.pop(0))
+            return sm.log_prob(x[rows].contiguous(), **kw)
+        fixed = run(1.0, method="rk4", options=opts)
+        assert torch.isfinite(fixed).all() or kind == "xtrace"          # (two equal probes among 2^16 samples: XTrace divides by ~0 there)
+        ok = torch.isfinite(fixed)
+        assert ok.float().mean() > 0.999
+        assert torch.equal(run(-1.0, method="rk4", options=opts)[ok], fixed[ok])
+        assert torch.equal(run(1.0, method="rk4", options=opts)[ok], fixed[ok])
+        part = run(1.0, rows=slice(1000, 3333), method="rk4", options=opts)
+        assert torch.equal(part[ok[1000:3333]], fixed[1000:3333][ok[1000:3333]])
+        if kind == "hutchpp":                                           # the reference's default solver: a re-run is bitwise equal
+            a, b = run(1.0), run(1.0)
+            assert torch.equal(a, b) and torch.isfinite(a).all() and sm.last_solver_stats["chunks"] <= 2
+            assert torch.equal(run(-1.0), a)
+    sm.hutchpp = sm.xtrace = False
