@@ -527,3 +527,45 @@ def test_two_host_threads_on_two_streams():
     for t in ts:
         t.join(600)
     assert not errors and not bad, (errors, bad)
+
+
+def test_default_adaptive_solves_against_scipys_integrator():
+    """An anchor that is nobody's restatement of torchdiffeq: scipy's own RK45 (`solve_ivp`, rtol 1e-10) integrates the
+    ORACLE's float64 right-hand side -- the reference's formulas, pinned by its fixtures -- to convergence; the product's
+    adaptive solves of the same problem (dopri5 on the device controller, the other pairs, dopri8 stage by stage) must land
+    within their tolerance of that answer, for sampling (decreasing span) and for the exact-trace log-density."""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    sm, _, so64 = _seeded_score_model(4, 0, [64, 64], "VESDE", False, 333)
+    torch.manual_seed(1)
+    B, D = 12, 4
+    base = torch.randn(B, D)
+    eps = float(torch.tensor(float(sm.sde.epsilon), dtype=torch.float32))
+
+    def f_state(t, y):
+        x = torch.from_numpy(y.reshape(B, D).copy())
+        (xd,) = so64.rhs(torch.tensor(t, dtype=torch.float64), (x,), None, None)
+        return xd.reshape(-1).numpy()
+    z = (base.double() * float(sm.sde.sigma_max)).reshape(-1).numpy()
+    conv = solve_ivp(f_state, (1.0, eps), z, method="RK45", rtol=1e-10, atol=1e-12)
+    assert conv.success
+    want = torch.from_numpy(conv.y[:, -1].reshape(B, D)).float()
+    for method, tol, bar in (("dopri5", 1e-6, 2e-5), ("bosh3", 1e-5, 5e-4), ("dopri8", 1e-6, 2e-5), ("dopri5", 1e-4, 2e-3)):
+        x, _ = sm.sample_ode_from_base(base.to(DEV), method=method, atol=tol, rtol=tol)
+        assert _state_err(x, want) < bar, (method, tol, _state_err(x, want))
+
+    x0 = torch.randn(B, D) * 0.5
+
+    def f_logp(t, y):
+        x = torch.from_numpy(y[: B * D].reshape(B, D).copy())
+        xd, div = so64.rhs(torch.tensor(t, dtype=torch.float64), (x, torch.zeros(B, 1, dtype=torch.float64)), None, "exact", None)
+        return np.concatenate([xd.detach().reshape(-1).numpy(), div.detach().reshape(-1).numpy()])
+    y0 = np.concatenate([x0.double().reshape(-1).numpy(), np.zeros(B)])
+    conv = solve_ivp(f_logp, (eps, 1.0), y0, method="RK45", rtol=1e-10, atol=1e-12)
+    assert conv.success
+    xT = torch.from_numpy(conv.y[: B * D, -1].reshape(B, D))
+    from oracle import flowfusion_oracle as O
+    want_lp = torch.from_numpy(conv.y[B * D:, -1]).reshape(B, 1) + O.normal_log_prob(xT, so64.sde.prior_scale()).sum(1, keepdim=True)
+    for method, tol, bar in (("dopri5", 1e-6, 2e-5), ("dopri5", 1e-4, 2e-3), ("adaptive_heun", 1e-5, 2e-3)):
+        lp = sm.log_prob(x0.to(DEV), method=method, atol=tol, rtol=tol)
+        assert _logp_err(lp, want_lp.float()) < bar, (method, tol, _logp_err(lp, want_lp.float()))

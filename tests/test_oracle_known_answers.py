@@ -367,3 +367,45 @@ def test_dopri8_dense_output_does_not_lean_on_the_restated_midpoint():
     s4.tab = broken
     y_bad, _ = s4.integrate(0.0, 1.27, y0.clone(), None)
     assert float((y_bad.double() - exact(1.27)).abs().max()) > 100 * max(err, 1e-7)
+
+
+def test_oracle_adaptive_solves_converge_to_scipys_integration():
+    """The oracle's restated adaptive steppers against an integrator nobody here wrote: scipy's `solve_ivp` (RK45, rtol 1e-11)
+    on the same float64 right-hand side -- a random-init score model's probability-flow ODE, decreasing span, and its
+    exact-trace log-density.  Every pair must land within a small multiple of its tolerance of the converged answer."""
+    import numpy as np
+    from scipy.integrate import solve_ivp
+    torch.manual_seed(21)
+    D, B = 3, 6
+    params = O.MLPParams(W=torch.randn(4) * 16, pi=torch.tensor(math.pi),
+                         weights=[torch.randn(32, 8 + D) * 0.3, torch.randn(32, 32) * 0.2, torch.randn(D, 32) * 0.2],
+                         biases=[torch.randn(32) * 0.1, torch.randn(32) * 0.1, torch.randn(D) * 0.1])
+    so = O.ScoreOracle(params, O.VE(dtype=torch.float64), no_sigma=False, dtype=torch.float64)
+    eps = float(so.sde.epsilon.to(torch.float32))
+    base = torch.randn(B, D, dtype=torch.float64)
+
+    def f(t, y):
+        (xd,) = so.rhs(torch.tensor(t, dtype=torch.float64), (torch.from_numpy(y.reshape(B, D).copy()),), None, None)
+        return xd.reshape(-1).numpy()
+    conv = solve_ivp(f, (1.0, eps), (base * so.sde.base_scale).reshape(-1).numpy(), method="RK45", rtol=1e-11, atol=1e-13)
+    assert conv.success
+    want = torch.from_numpy(conv.y[:, -1].reshape(B, D))
+    scale = float(want.abs().max())
+    for method, tol, bar in (("dopri5", 1e-8, 1e-6), ("dopri5", 1e-5, 1e-3), ("bosh3", 1e-6, 1e-4), ("fehlberg2", 1e-5, 1e-3),
+                             ("adaptive_heun", 1e-5, 1e-3), ("dopri8", 1e-9, 1e-7)):
+        got = so.sample_ode_from_base(base, None, method, None, tol, tol)
+        assert float((got - want).abs().max()) / scale < bar, (method, tol, float((got - want).abs().max()) / scale)
+
+    x0 = torch.randn(B, D, dtype=torch.float64) * 0.5
+
+    def g(t, y):
+        x = torch.from_numpy(y[: B * D].reshape(B, D).copy())
+        xd, div = so.rhs(torch.tensor(t, dtype=torch.float64), (x, torch.zeros(B, 1, dtype=torch.float64)), None, "exact", None)
+        return np.concatenate([xd.detach().reshape(-1).numpy(), div.detach().reshape(-1).numpy()])
+    conv = solve_ivp(g, (eps, 1.0), np.concatenate([x0.reshape(-1).numpy(), np.zeros(B)]), method="RK45", rtol=1e-11, atol=1e-13)
+    assert conv.success
+    xT = torch.from_numpy(conv.y[: B * D, -1].reshape(B, D))
+    want_lp = torch.from_numpy(conv.y[B * D:, -1]).reshape(B, 1) + O.normal_log_prob(xT, so.sde.prior_scale()).sum(1, keepdim=True)
+    for method, tol, bar in (("dopri5", 1e-8, 1e-6), ("bosh3", 1e-6, 1e-4)):
+        lp = so.log_prob(x0, None, method, None, "exact", None, tol, tol)
+        assert float(((lp - want_lp).abs() / want_lp.abs().clamp_min(1.0)).max()) < bar, (method, tol)
