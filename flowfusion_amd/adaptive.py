@@ -160,18 +160,19 @@ class Dopri5:
     """Batch-global adaptive Dormand-Prince over an increasing solver-time span [t0, t1]."""
 
     def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None,
-                 norm_only=(), method: str = "dopri5"):
+                 norm_only=(), method: str = "dopri5", sign: float = 1.0):
         """``norm_only``: components the reference carries in the tuple state with a zero derivative (the raw
         ``conditional`` of ConditionalODEFlow, flow.py:779-796, 855-881).  Under the mixed norm they can only
         matter where the state itself is measured -- d0 of the initial step; their derivative and error
-        estimate are identically zero."""
+        estimate are identically zero.  ``sign`` = -1 for a decreasing span (solved in negated time): the options that
+        name TIMES (``step_t``, ``jump_t``) are negated with it, as torchdiffeq's ``_check_inputs`` does."""
         if method not in TABLEAUX:
             raise NotImplementedError(f"adaptive method {method!r}: {sorted(TABLEAUX)} run one launch per attempted step; "
                                       f"{sorted(WIDE_TABLEAUX)} have more stages than the 7 slots the fused kernels keep on chip "
                                       "and take adaptive.HostSteppedPair (adaptive.make_solver picks)")
         self.tab = TABLEAUX[method]
         self.step = step
-        self._init_control(has_lp, rtol, atol, options, norm_only)
+        self._init_control(has_lp, rtol, atol, options, norm_only, sign)
         # the tableau as fp32 tensors, once per solve (an attempt then costs a handful of host tensor ops instead of ~40)
         S = self.tab.stages
         self._alpha = _f32(self.tab.alpha)
@@ -184,9 +185,12 @@ class Dopri5:
         self._last_stage = _onehot(S - 1)
         self._stage_slots = torch.arange(1, S, dtype=torch.int32)
 
-    def _init_control(self, has_lp, rtol, atol, options, norm_only):
+    def _init_control(self, has_lp, rtol, atol, options, norm_only, sign=1.0):
         """Tolerances and torchdiffeq's step-control options (shared by the one-launch-per-attempt and the stage-by-stage
-        drivers)."""
+        drivers).  ``step_t`` (times a step must END on), ``jump_t`` (the same, and the derivative is re-evaluated just
+        behind them: discontinuities of the right-hand side) and ``norm`` (a callable on the tuple state replacing the
+        mixed RMS norm) are what torchdiffeq's RKAdaptiveStepsizeODESolver takes besides the step-size limits; the host
+        controller serves them (device_adaptive.supported sends such solves here)."""
         opts = dict(options or {})
         self.norm_only = [c for c in norm_only if c is not None and c.numel() > 0]
         self.has_lp = has_lp
@@ -198,9 +202,12 @@ class Dopri5:
         self.max_num_steps = int(opts.pop("max_num_steps", 2 ** 31 - 1))
         if opts.get("dtype") not in (None, torch.float64):      # torchdiffeq's time dtype: float64 is its default and what runs here
             raise NotImplementedError("adaptive option dtype: time is kept in float64 (torchdiffeq's default); other dtypes are not built")
-        for k in ("step_t", "jump_t", "norm"):
-            if opts.get(k) is not None:
-                raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
+        def tvals(v):       # torchdiffeq `_sort_tvals` happens in integrate (it needs t0); here: float64, solver time
+            return None if v is None else (float(sign) * torch.as_tensor(v, dtype=torch.float64).detach().reshape(-1).cpu())
+        self.step_t, self.jump_t = tvals(opts.pop("step_t", None)), tvals(opts.pop("jump_t", None))
+        self.norm_fn = opts.pop("norm", None)
+        if self.norm_fn is not None and not callable(self.norm_fn):
+            raise TypeError("options['norm'] must be a callable taking the tuple state and returning a scalar")
         self.n_attempts = 0
         self.n_accepted = 0
 
@@ -235,7 +242,7 @@ class Dopri5:
         and whether `check` holds a non-finite value.  On the GPU: one ff_scaled_rms launch and one read-back, the
         only host synchronisation of an attempted step.  (CPU tensors -- the kernel-semantics emulator of the tests --
         take the same arithmetic in torch ops.)"""
-        if terms[0][0].is_cuda:
+        if terms[0][0].is_cuda and self.norm_fn is None:
             from . import _native, distributed
             exchange, group = distributed.step_control_group()
             out = []
@@ -264,10 +271,25 @@ class Dopri5:
         exchange, group = distributed.step_control_group()
         if exchange and check is not None:
             bad = distributed.sum_over_ranks([1.0 if bad else 0.0], check.device, group)[0] > 0
-        return _mixed_norm(parts), bad
+        return self._norm_of(parts), bad
+
+    def _norm_of(self, parts, mids=None) -> float:
+        """The norm of the scaled components ``parts`` = [y] or [y, lp]: torchdiffeq's mixed norm, or the user's
+        ``options["norm"]`` on the tuple as the reference's state has it -- (x, delta_logp [B, 1]) for the score models
+        (diffusion.py:744-752), (x[, conditional], logJ [B, 1]) for the flows (flow.py:371-382, 869-881).  ``mids``: the
+        scaled values of the components carried with a zero derivative (they sit between the state and the divergence);
+        None where a derivative or an error estimate is measured: zeros."""
+        if self.norm_fn is None:
+            return _mixed_norm(list(parts) + list(mids or []))
+        from . import distributed
+        if distributed.step_control_group()[0]:
+            raise NotImplementedError("options['norm'] with distributed.global_step_control: a user norm cannot be summed over ranks")
+        mids = list(mids) if mids is not None else [torch.zeros_like(c) for c in self.norm_only]
+        tup = [parts[0]] + mids + ([parts[1].reshape(-1, 1)] if self.has_lp else [])
+        return float(self.norm_fn(tuple(tup)))
 
     def _select_initial_step(self, t0, y, lp, f0, fl0):
-        if y.is_cuda:
+        if y.is_cuda and self.norm_fn is None:
             ys = [p for p in (y, lp) if p is not None]
             fs = [p for p in (f0, fl0) if p is not None]
             d0, _ = self._norms([(a, None, a, None) for a in ys] + [(c, None, c, None) for c in self.norm_only])
@@ -285,14 +307,15 @@ class Dopri5:
         scale = [self.atol + p.abs() * self.rtol for p in (y, lp) if p is not None]
         ys = [p for p in (y, lp) if p is not None]
         fs = [p for p in (f0, fl0) if p is not None]
-        d0 = _mixed_norm([a / s for a, s in zip(ys, scale)] +
-                         [c / (self.atol + c.abs() * self.rtol) for c in self.norm_only])
-        d1 = _mixed_norm([a / s for a, s in zip(fs, scale)])
+        cs = [c / (self.atol + c.abs() * self.rtol) for c in self.norm_only]
+        scaled_y = [a / s for a, s in zip(ys, scale)]
+        d0 = self._norm_of(scaled_y, cs)
+        d1 = self._norm_of([a / s for a, s in zip(fs, scale)])
         h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
         h0 = float(_f32(abs(h0)))
         f1, fl1 = self._deriv(float(_f32(t0)) + h0, y, lp, k1=f0, kl1=fl0, h=h0)
         f1s = [p for p in (f1, fl1) if p is not None]
-        d2 = abs(_mixed_norm([(a - b) / s for a, b, s in zip(f1s, fs, scale)]) / h0)
+        d2 = abs(self._norm_of([(a - b) / s for a, b, s in zip(f1s, fs, scale)]) / h0)
         if d1 <= 1e-15 and d2 <= 1e-15:
             h1 = max(1e-6, h0 * 1e-3)
         else:
@@ -330,6 +353,17 @@ class Dopri5:
         t_lo, t_hi = t0, t0                      # rk_state.t0, rk_state.t1
         interp = None
         n_steps = 0
+        # options step_t / jump_t (torchdiffeq `_before_integrate`: `_sort_tvals` keeps the times >= t0, sorted; the two lists
+        # must not share an element; the index of the next one by bisection)
+        import bisect
+        import numpy as np
+        sort_t = lambda v: [] if v is None else sorted(float(u) for u in v.tolist() if float(u) >= t0)
+        step_t, jump_t = sort_t(self.step_t), sort_t(self.jump_t)
+        both = step_t + jump_t
+        if len(set(both)) != len(both):
+            raise ValueError("`step_t` and `jump_t` must not have any repeated elements between them.")
+        i_step = min(bisect.bisect(step_t, t0), len(step_t) - 1)
+        i_jump = min(bisect.bisect(jump_t, t0), len(jump_t) - 1)
         while t_end > t_hi:
             if n_steps >= self.max_num_steps:
                 raise self._fail(f"max_num_steps exceeded ({n_steps}>={self.max_num_steps})")
@@ -338,6 +372,19 @@ class Dopri5:
             ta, tb = t_hi, t_hi + dt
             if not (ta + dt > ta):      # also catches dt = NaN after a non-finite error estimate
                 raise self._fail(f"underflow in dt {dt}")
+            # a step that would cross the next step_t / jump_t ends ON it (`_adaptive_step`)
+            on_step_t = on_jump_t = False
+            if step_t:
+                on_step_t = ta < step_t[i_step] < ta + dt
+                if on_step_t:
+                    tb = step_t[i_step]
+                    dt = tb - ta
+            if jump_t:
+                on_jump_t = ta < jump_t[i_jump] < ta + dt
+                if on_jump_t:
+                    on_step_t = False
+                    tb = jump_t[i_jump]
+                    dt = tb - ta
             aux, aux_lp = self._attempt(ta, dt, tb, y, lp, f0, fl0)
             self.n_attempts += 1
             y1, f1, ymid, yerr = aux[0], aux[1], aux[2], aux[3]
@@ -363,6 +410,16 @@ class Dopri5:
                 y, f0 = y1, f1
                 if self.has_lp:
                     lp, fl0 = lp1, fl1
+                if on_step_t and i_step != len(step_t) - 1:
+                    i_step += 1
+                if on_jump_t:
+                    if i_jump != len(jump_t) - 1:
+                        i_jump += 1
+                    # just past a discontinuity of the right-hand side: the derivative of the side we are on now --
+                    # torchdiffeq evaluates `func(t_next, y_next, perturb=Perturb.NEXT)`, i.e. at the next representable
+                    # time of the STATE's dtype (fp32) in solver time
+                    t_after = float(np.nextafter(np.float32(tb), np.float32(np.inf)))
+                    f0, fl0 = self._deriv(t_after, y, lp)
             dt = self._optimal_step_size(dt, ratio)
             if dt == dt:
                 dt = min(max(dt, self.min_step), self.max_step)
@@ -429,12 +486,12 @@ class HostSteppedPair(Dopri5):
     nothing against the evaluations; at notebook sizes it is launch-bound (~40 launches per attempt)."""
 
     def __init__(self, step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None,
-                 norm_only=(), method: str = "dopri8"):
+                 norm_only=(), method: str = "dopri8", sign: float = 1.0):
         if method not in WIDE_TABLEAUX:
             raise NotImplementedError(f"stage-by-stage stepping is for {sorted(WIDE_TABLEAUX)}; {method!r} runs on Dopri5")
         self.tab = WIDE_TABLEAUX[method]
         self.step = step
-        self._init_control(has_lp, rtol, atol, options, norm_only)
+        self._init_control(has_lp, rtol, atol, options, norm_only, sign)
         self._slot0 = torch.zeros(1, dtype=torch.int32)
         self._cin0 = torch.zeros(1, 8)
         self._tail0 = torch.stack([_onehot(0), torch.zeros(8), torch.zeros(8), torch.zeros(8)])
@@ -469,10 +526,10 @@ class HostSteppedPair(Dopri5):
 
 
 def make_solver(step: StepFn, has_lp: bool, rtol: float, atol: float, options: Optional[dict] = None, norm_only=(),
-                method: str = "dopri5") -> Dopri5:
+                method: str = "dopri5", sign: float = 1.0) -> Dopri5:
     """The adaptive driver for ``method``: one launch per attempted step (``Dopri5``) for the pairs whose stages fit the
     fused kernels' slots, stage by stage (``HostSteppedPair``) for ``dopri8``.  ``step`` has the contract of
     ``FusedNet.make_step`` / ``generic.ModuleStepper.make_step`` / ``host_stepper.RowStepper.make_step`` either way."""
     if method in WIDE_TABLEAUX:
-        return HostSteppedPair(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method)
-    return Dopri5(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method)
+        return HostSteppedPair(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method, sign=sign)
+    return Dopri5(step, has_lp, rtol, atol, options, norm_only=norm_only, method=method, sign=sign)

@@ -55,11 +55,17 @@ def host_controller_forced() -> bool:
     return os.environ.get("FF_HOST_CONTROLLER", "") not in ("", "0")
 
 
-def supported(spec: Optional[ScheduleSpec], x: torch.Tensor, net=None, mode: int = MODE_STATE) -> bool:
-    """The device controller can run this solve: a schedule it knows, at most 64 time columns in the first layer, and -- for
-    the exact trace -- at most FF_ADAPT_MAX_PASSES unit-tangent passes per attempted step (more than 120 dimensions on the
-    16-column tile).  Otherwise the host controller takes it."""
+HOST_ONLY_OPTIONS = ("step_t", "jump_t", "norm")      # torchdiffeq options only the host controller serves (adaptive.py)
+
+
+def supported(spec: Optional[ScheduleSpec], x: torch.Tensor, net=None, mode: int = MODE_STATE, options: Optional[dict] = None) -> bool:
+    """The device controller can run this solve: a schedule it knows, at most 64 time columns in the first layer, none of
+    the options that need the host (``step_t`` / ``jump_t``: steps ending on given times; ``norm``: a Python callable) and
+    -- for the exact trace -- at most FF_ADAPT_MAX_PASSES unit-tangent passes per attempted step (more than 120 dimensions
+    on the 16-column tile).  Otherwise the host controller takes it."""
     if spec is None or not x.is_cuda or host_controller_forced() or spec.w0t.shape[1] > MAX_TIME_COLS:
+        return False
+    if any((options or {}).get(k) is not None for k in HOST_ONLY_OPTIONS):
         return False
     if net is not None and mode == MODE_EXACT and len(list(_passes(net, net.plan(mode)))) > _native.ADAPT_MAX_PASSES:
         return False
@@ -92,9 +98,9 @@ def build_config(spec: ScheduleSpec, sign: float, method: str, rtol: float, atol
     c.max_num_steps = int(min(opts.pop("max_num_steps", 2 ** 31 - 1), 2 ** 31 - 1))
     if opts.get("dtype") not in (None, torch.float64):          # torchdiffeq's time dtype: float64 is its default and what runs here
         raise NotImplementedError("adaptive option dtype: time is kept in float64 (torchdiffeq's default); other dtypes are not built")
-    for k in ("step_t", "jump_t", "norm"):
+    for k in HOST_ONLY_OPTIONS:
         if opts.get(k) is not None:
-            raise NotImplementedError(f"dopri5 option {k!r} is not supported on the fused path")
+            raise NotImplementedError(f"adaptive option {k!r} runs on the host controller (adaptive.py): device_adaptive.supported() says so")
     c.sched, c.no_sigma, c.sign = spec.sched, int(bool(spec.no_sigma)), float(sign)
     for i, v in enumerate(spec.p):
         c.p[i] = float(v)

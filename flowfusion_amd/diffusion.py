@@ -398,7 +398,7 @@ class ScoreModel(nn.Module):
             t = t_span.detach().to("cpu", torch.float32).double()
             sign = -1.0 if bool(t[0] > t[-1]) else 1.0
             spec = self._device_schedule(x.device) if (x.is_cuda and method in solvers.NATIVE_ADAPTIVE) else None
-            if device_adaptive.supported(spec, x, net, mode):
+            if device_adaptive.supported(spec, x, net, mode, options):
                 # the whole loop on the device: attempts, error norms, step control, the next attempt's table rows
                 y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]),
                                                      rtol, atol, options, method, cond=cond, probe=probe)
@@ -409,7 +409,7 @@ class ScoreModel(nn.Module):
             host = self._schedule_inputs()
             sched = lambda tr: self._schedule(tr, "ode", host)[:3]
             step = net.make_step(sched, sign, mode, x.device, cond=cond, probe=probe)
-            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, method=method)
+            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, method=method, sign=sign)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)
@@ -710,7 +710,7 @@ class ScoreModel(nn.Module):
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)
         if method in solvers.ALL_ADAPTIVE:
             spec = self._device_schedule(x.device) if method in solvers.NATIVE_ADAPTIVE else None
-            if device_adaptive.supported(spec, x, net, MODE_EXACT) and \
+            if device_adaptive.supported(spec, x, net, MODE_EXACT, options) and \
                     device_adaptive.estimator_bytes(net, method, B, kind, probes) <= self._estimator_budget(x.device):
                 y, lp, stats = device_adaptive.solve(net, spec, 1.0, MODE_EXACT, x, float(t_span[0]), float(t_span[1]), rtol, atol,
                                                      options, method, cond=conditional, estimator=(kind, probes))

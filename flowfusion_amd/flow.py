@@ -135,7 +135,7 @@ class _FlowBase(nn.Module):
                 D = self.target_dimension
                 w0t, b0 = net.time_columns(x.device, D, D + 1)
                 spec = device_adaptive.ScheduleSpec(_native.SCHED_FLOW, (0.0, 0.0, 0.0), True, None, 0.0, w0t, b0)
-            if device_adaptive.supported(spec, x, net, mode):
+            if device_adaptive.supported(spec, x, net, mode, options):
                 # the whole loop on the device (device_adaptive.py): xdot = NET([x, t, cond]) -> a = 0, b = 1, c1 = w_t t + b1
                 y, lp, stats = device_adaptive.solve(net, spec, sign, mode, x, float(sign * t[0]), float(sign * t[-1]), rtol, atol,
                                                      options, method, cond=cond, probe=probe, norm_only=extra)
@@ -143,7 +143,7 @@ class _FlowBase(nn.Module):
                 return y, lp
             first = net.first_layer_cpu()
             step = net.make_step(lambda tr: self._schedule(tr, first), sign, mode, x.device, cond=cond, probe=probe)
-            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method)
+            solver = adaptive.make_solver(step, mode != MODE_STATE, rtol, atol, options, norm_only=extra, method=method, sign=sign)
             lp0 = torch.zeros(x.shape[0], device=x.device) if mode != MODE_STATE else None
             y, lp = solver.integrate(float(sign * t[0]), float(sign * t[-1]),
                                      x.detach().to(torch.float32).contiguous(), lp0)

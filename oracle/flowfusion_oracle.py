@@ -537,8 +537,14 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     cast to the state dtype, one step size for the whole batch chosen from the mixed RMS norm of
     err / (atol + rtol * max(|y0|, |y1|)), safety 0.9, growth <= 10, shrink >= 0.2, initial step by
     Hairer's rule, and the value at ``t[-1]`` read off the 4th-order dense output of the last step.
+    Options besides the step-size limits (`_before_integrate` / `_adaptive_step`): ``step_t`` -- times a step must end on;
+    ``jump_t`` -- the same, and the derivative is re-evaluated just behind them (``perturb=Perturb.NEXT``: the next
+    representable time of the state's dtype); ``norm`` -- a callable on the tuple state replacing the mixed norm.  For a
+    decreasing span `_check_inputs` negates the two time lists together with ``t``.
     """
+    import bisect
     opts = dict(options or {})
+    norm = opts.get("norm") or _tuple_norm
     min_step = float(opts.get("min_step", 0.0))
     max_step = float(opts.get("max_step", float("inf")))
     if method == "dopri5":
@@ -546,8 +552,10 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     else:
         order, ALPHA, BETA, C_SOL, C_ERR, C_MID = _ADAPTIVE_TABLEAUX[method]
     t = t.double()
+    flip = 1.0
     if bool(t[0] > t[-1]):
         t = -t
+        flip = -1.0
         base = func
         func = lambda tt, yy: tuple(-f for f in base(-tt, yy))
     dty = y0[0].dtype
@@ -560,13 +568,13 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     first_step = opts.get("first_step")
     max_num_steps = int(opts.get("max_num_steps", 2 ** 31 - 1))
     scale = tuple(atol + a.abs() * rtol for a in y0)
-    d0 = _tuple_norm([a / s for a, s in zip(y0, scale)])
-    d1 = _tuple_norm([a / s for a, s in zip(f0, scale)])
+    d0 = norm(tuple(a / s for a, s in zip(y0, scale)))
+    d1 = norm(tuple(a / s for a, s in zip(f0, scale)))
     h0 = torch.tensor(1e-6, dtype=dty) if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
     h0 = h0.abs()
     y1 = tuple(a + h0 * b for a, b in zip(y0, f0))
     f1 = func(t0.to(dty) + h0, y1)
-    d2 = (_tuple_norm([(a - b) / s for a, b, s in zip(f1, f0, scale)]) / h0).abs()
+    d2 = (norm(tuple((a - b) / s for a, b, s in zip(f1, f0, scale))) / h0).abs()
     if d1 <= 1e-15 and d2 <= 1e-15:
         h1 = torch.max(torch.tensor(1e-6, dtype=dty), h0 * 1e-3)
     else:
@@ -580,6 +588,16 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
     last = None
     last_adaptive_stats.update(attempts=0, accepted=0, steps=[])      # steps: (t, dt, error ratio, accepted) per attempt
     n_steps = 0
+
+    def sort_tvals(v):                                            # `_sort_tvals`: the times >= t0, ascending
+        if v is None:
+            return []
+        return sorted(u for u in (flip * torch.as_tensor(v, dtype=torch.float64).reshape(-1)).tolist() if u >= float(t0))
+    step_t, jump_t = sort_tvals(opts.get("step_t")), sort_tvals(opts.get("jump_t"))
+    if len(set(step_t + jump_t)) != len(step_t + jump_t):
+        raise ValueError("`step_t` and `jump_t` must not have any repeated elements between them.")
+    i_step = min(bisect.bisect(step_t, float(t0)), len(step_t) - 1)
+    i_jump = min(bisect.bisect(jump_t, float(t0)), len(jump_t) - 1)
     while t[-1] > t_hi:
         assert n_steps < max_num_steps, f"max_num_steps exceeded ({n_steps}>={max_num_steps})"
         n_steps += 1
@@ -587,6 +605,18 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
         ta, tb = t_hi, t_hi + dt
         if not bool(ta + dt > ta):
             raise AssertionError(f"underflow in dt {float(dt)}")  # torchdiffeq's assertion
+        on_step_t = on_jump_t = False
+        if step_t:
+            on_step_t = bool(ta < step_t[i_step] < ta + dt)
+            if on_step_t:
+                tb = torch.as_tensor(step_t[i_step], dtype=torch.float64)
+                dt = tb - ta
+        if jump_t:
+            on_jump_t = bool(ta < jump_t[i_jump] < ta + dt)
+            if on_jump_t:
+                on_step_t = False
+                tb = torch.as_tensor(jump_t[i_jump], dtype=torch.float64)
+                dt = tb - ta
         ta32, dt32, tb32 = ta.to(dty), dt.to(dty), tb.to(dty)
         ks = [f]
         for alpha, beta in zip(ALPHA, BETA):
@@ -597,7 +627,7 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
         f1 = ks[-1]
         err = comb(ks, C_ERR, dt32)
         tol = tuple(atol + rtol * torch.max(a.abs(), b.abs()) for a, b in zip(y, y1))
-        ratio = _tuple_norm([e / s for e, s in zip(err, tol)]).abs()
+        ratio = torch.as_tensor(norm(tuple(e / s for e, s in zip(err, tol)))).abs()
         last_adaptive_stats["attempts"] += 1
         accept = bool(ratio <= 1)
         if dt > max_step:
@@ -611,6 +641,12 @@ def odeint_dopri5(func, y0, t, rtol=1e-7, atol=1e-9, options=None, method="dopri
             last_adaptive_stats["accepted"] += 1
             t_lo, t_hi = ta, tb
             y, f = y1, f1
+            if on_step_t and i_step != len(step_t) - 1:
+                i_step += 1
+            if on_jump_t:
+                if i_jump != len(jump_t) - 1:
+                    i_jump += 1
+                f = func(torch.nextafter(tb32, tb32 + 1), y)      # the side of the discontinuity we are on now
         ratio = ratio.double()
         if bool(torch.isnan(ratio)):
             raise AssertionError("underflow in dt nan")       # what torchdiffeq's next attempt asserts

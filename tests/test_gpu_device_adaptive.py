@@ -191,8 +191,17 @@ def test_options_and_assertions_match_the_host_controller(monkeypatch):
     assert ma == mb == "max_num_steps exceeded (4>=4)" and _same_counts(sa, sb) and sa["attempts"] == 4
     with pytest.raises(NotImplementedError, match="multistep"):
         sm.sample_ode_from_base(base.to(DEV), method="implicit_adams")
-    with pytest.raises(NotImplementedError, match="step_t"):
-        sm.sample_ode_from_base(base.to(DEV), options={"step_t": torch.tensor([0.5])})
+    # step_t / jump_t / norm need the host (steps ending on given times, a Python callable): such solves take the host
+    # controller by themselves, and agree with the oracle run with the same options
+    for opts in ({"step_t": torch.tensor([0.5, 0.25])}, {"jump_t": [0.7], "step_t": [0.1]},
+                 {"norm": lambda state: max(c.abs().max() for c in state)}):
+        x, _ = sm.sample_ode_from_base(base.to(DEV), options=dict(opts))
+        assert "chunks" not in sm.last_solver_stats and sm.last_solver_stats["accepted"] >= 3
+        assert _state_err(x, so32.sample_ode_from_base(base, None, "dopri5", dict(opts))) < ADAPT_TOL, list(opts)
+    lp = sm.log_prob(base.to(DEV) * 0.5, options={"min_step": 1e-6, "norm": lambda state: max(c.abs().max() for c in state)})
+    assert "chunks" not in sm.last_solver_stats
+    ref = so32.log_prob(base * 0.5, None, "dopri5", {"min_step": 1e-6, "norm": lambda state: max(c.abs().max() for c in state)}, "exact", None)
+    assert _logp_err(lp, ref) < ADAPT_TOL
 
 
 def test_diverging_vp_reverse_flow_is_pinned_on_both_sides(monkeypatch):

@@ -713,3 +713,76 @@ def test_launch_kind_states_the_launchers_rule(built_library, monkeypatch):
     assert _native.launch_kind(pw, 1 << 18, 0) == T
     with pytest.raises(RuntimeError, match="FF_ERR_BADARG"):
         _native.launch_kind(p0, -1, 0)
+
+
+def test_adaptive_options_step_t_jump_t_norm(built_library):
+    """torchdiffeq's remaining adaptive options on the host controller (the reference hands `options` through untouched,
+    diffusion.py:631-639, 744-752): `step_t` -- accepted steps END on the given times; `jump_t` -- the same and one more
+    right-hand side per jump; `norm` -- a user callable on the tuple state (x, delta_logp [B, 1]).  Kernel-semantics
+    emulator against the oracle's restatement (decreasing span: the time lists are negated with it), attempt for attempt;
+    and against a property neither restatement can fake: with the max-norm as `norm` every component's scaled error
+    stays below 1 in every accepted step."""
+    from flowfusion_amd import adaptive
+    torch.manual_seed(8)
+    meta = dict(D=3, C=0, E=8, units=[64, 64], sde="VESDE", sde_kw={}, no_sigma=False)
+    sm = D.ScoreModel(D.MLP(3, 0, 8, [64, 64]), D.VESDE(), no_sigma=False).eval()
+    so = score_oracle(meta, {k: v.detach().clone() for k, v in sm.state_dict().items()}, torch.float64)
+    net = sm._net()
+    B = 6
+    eps = float(torch.tensor(float(sm.sde.epsilon), dtype=torch.float32))
+    sched = lambda tr: sm._schedule(tr, "ode")[:3]
+    z = torch.randn(B, 3) * float(sm.sde.sigma_max)
+
+    # sampling, decreasing span 1 -> eps: step_t / jump_t are REAL times, negated inside
+    def sample(options):
+        step = net.make_step(sched, -1.0, MODE_STATE, "cpu", launcher=_cpu_launcher(net, MODE_STATE))
+        solver = adaptive.make_solver(step, False, 1e-5, 1e-5, dict(options), method="dopri5", sign=-1.0)
+        seen = []
+        orig = solver._attempt
+        solver._attempt = lambda ta, dt, tb, *a: (seen.append((ta, tb)), orig(ta, dt, tb, *a))[1]
+        y, _ = solver.integrate(-1.0, -eps, z.clone(), None)
+        return y, solver, seen
+    plain, s0, _ = sample({})
+    pts = [0.75, 0.4, 0.9, 1.5]                                      # (1.5 lies outside the span: ignored)
+    y, s1, seen = sample({"step_t": torch.tensor(pts)})
+    ends = {round(-tb, 12) for _, tb in seen}
+    f32 = lambda v: round(float(torch.tensor(v, dtype=torch.float32)), 12)      # (the option came as an fp32 tensor)
+    assert {f32(0.9), 0.75, f32(0.4)} <= ends and s1.n_accepted >= s0.n_accepted
+    ref = so.sample_ode_from_base((z / sm.sde.sigma_max).double(), None, "dopri5", {"step_t": torch.tensor(pts)}, 1e-5, 1e-5)
+    assert O.last_adaptive_stats["attempts"] == s1.n_attempts and O.last_adaptive_stats["accepted"] == s1.n_accepted
+    assert max_rel(y, ref, floor=ref.abs().max().item()) < 5e-5
+    assert max_rel(y, plain, floor=plain.abs().max().item()) < 1e-3      # the same solution, other steps
+    yj, sj, seenj = sample({"jump_t": [0.6], "step_t": [0.3]})
+    assert {0.6, 0.3} <= {round(-tb, 12) for _, tb in seenj}
+    refj = so.sample_ode_from_base((z / sm.sde.sigma_max).double(), None, "dopri5", {"jump_t": [0.6], "step_t": [0.3]}, 1e-5, 1e-5)
+    assert (O.last_adaptive_stats["attempts"], O.last_adaptive_stats["accepted"]) == (sj.n_attempts, sj.n_accepted)
+    assert max_rel(yj, refj, floor=refj.abs().max().item()) < 5e-5
+    with pytest.raises(ValueError, match="repeated elements"):
+        sample({"jump_t": [0.6], "step_t": [0.6]})
+
+    # log-density, increasing span, user norm = max norm over the tuple (x, delta_logp [B, 1])
+    x0 = torch.randn(B, 3) * 0.5
+    e = torch.sign(torch.randn(B, 3))
+    shapes = []
+
+    def max_norm(state):
+        shapes.append(tuple(tuple(c.shape) for c in state))
+        return max(c.abs().max() for c in state)
+    step = net.make_step(sched, 1.0, MODE_HUTCH, "cpu", probe=e, launcher=_cpu_launcher(net, MODE_HUTCH, None, e))
+    solver = adaptive.make_solver(step, True, 1e-4, 1e-4, {"norm": max_norm, "min_step": 1e-9}, method="dopri5")
+    ratios = []
+    orig_norms = solver._norms
+    solver._norms = lambda terms, check=None: (lambda r: (ratios.append(r[0]) if check is not None else None, r)[1])(orig_norms(terms, check))
+    y, lp = solver.integrate(eps, 1.0, x0.clone(), torch.zeros(B))
+    assert set(shapes) == {((B, 3), (B, 1))}
+    xT, dlp = so.solve_odes_forward(x0.double(), None, "dopri5", {"norm": max_norm, "min_step": 1e-9}, "hutch", e.double(), 1e-4, 1e-4)
+    assert (O.last_adaptive_stats["attempts"], O.last_adaptive_stats["accepted"]) == (solver.n_attempts, solver.n_accepted)
+    assert max_rel(y, xT, floor=xT.abs().max().item()) < 2e-4 and max_rel(lp[:, None], dlp, floor=1.0) < 2e-4
+    # under the max norm an accepted step has EVERY scaled error component <= 1; the default RMS norm accepts steps whose
+    # worst component is above it -- so the max norm must have taken at least as many steps
+    step2 = net.make_step(sched, 1.0, MODE_HUTCH, "cpu", probe=e, launcher=_cpu_launcher(net, MODE_HUTCH, None, e))
+    rms = adaptive.make_solver(step2, True, 1e-4, 1e-4, {"min_step": 1e-9}, method="dopri5")
+    rms.integrate(eps, 1.0, x0.clone(), torch.zeros(B))
+    assert solver.n_accepted >= rms.n_accepted and len(ratios) == solver.n_attempts
+    with pytest.raises(TypeError, match="callable"):
+        adaptive.make_solver(step2, True, 1e-4, 1e-4, {"norm": "rms"}, method="dopri5")
