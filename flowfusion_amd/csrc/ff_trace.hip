@@ -9,8 +9,8 @@
 //
 // Roofline: HBM -- algorithmically one read of the Jacobians (4 D^2 bytes per work item) and 4 bytes written.
 //
-//   trace_estimate_tile_kernel<DC>   the fast path (D <= 16, and the tile fits LDS): one wavefront = 64 consecutive work
-//       items.  Their matrices are one contiguous stretch of memory: the wavefront streams it with coalesced loads (lane l
+//   trace_estimate_tile_kernel<DC, ITEMS>   the fast path (D <= 32, and the tile fits LDS): one wavefront = 64 consecutive work
+//       items (32 beyond 16 dimensions).  Their matrices are one contiguous stretch of memory: the wavefront streams it with coalesced loads (lane l
 //       takes element l of every 64) and scatters it into LDS TRANSPOSED to item-fastest with an odd pitch (65 words), so
 //       that both the scatter (consecutive elements of one matrix -> consecutive banks) and every later read (lane = item ->
 //       consecutive banks) are conflict-free.  The factorisation's scratch lives in LDS the same way.  Then each lane runs its
@@ -30,7 +30,8 @@
 
 namespace ff {
 
-constexpr int kTilePitch = 65;          // words between consecutive LDS rows of a 64-item tile (odd: conflict-free both ways)
+// words between consecutive LDS rows of a tile of ITEMS work items (odd: conflict-free both ways)
+__host__ __device__ constexpr int tile_pitch(int items) { return items + 1; }
 
 __global__ __launch_bounds__(256) void trace_estimate_kernel(const ff_trace_args a, long long items)
 {
@@ -51,24 +52,27 @@ __global__ __launch_bounds__(256) void trace_estimate_kernel(const ff_trace_args
     a.out[t] = trace::estimate<0>(a.kind, it);
 }
 
-// LDS words of a 64-item tile: matrices and scratch (the probes are read from global memory: with the operand vectors of
-// the products held in registers every probe entry is read once or twice)
-__host__ __device__ inline size_t tile_lds_words(int kind, int D, int r)
+// LDS words of a tile of `items` work items: matrices and scratch (the probes are read from global memory: with the operand
+// vectors of the products held in registers every probe entry is read once or twice)
+__host__ __device__ inline size_t tile_lds_words(int kind, int D, int r, int items)
 {
-    return (size_t)kTilePitch * ((size_t)D * D + trace::workspace_per_item(kind, D, r));
+    return (size_t)tile_pitch(items) * ((size_t)D * D + trace::workspace_per_item(kind, D, r));
 }
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));
 
-template <int DC>
+// ITEMS = work items per tile: 64 (one per lane) up to 16 dimensions; 32 for 17-32 dimensions, whose matrices are four times
+// the size (half the lanes only help with the staging: still far ahead of one dependent global load at a time)
+template <int DC, int ITEMS>
 __global__ __launch_bounds__(64) void trace_estimate_tile_kernel(const ff_trace_args a, long long items)
 {
     if (a.gate && *(const volatile int32_t*)a.gate == 0) return;
     extern __shared__ float tile[];
+    constexpr int kTilePitch = tile_pitch(ITEMS);
     const int D = DC ? DC : a.dim, DD = D * D;
     const int lane = threadIdx.x;
-    const long long t0 = (long long)blockIdx.x * 64;
-    const int n_here = (int)(items - t0 < 64 ? items - t0 : 64);
+    const long long t0 = (long long)blockIdx.x * ITEMS;
+    const int n_here = (int)(items - t0 < ITEMS ? items - t0 : ITEMS);
     float* const a_lds = tile;                                   // [D * D][pitch]
     float* const w_lds = a_lds + (size_t)DD * kTilePitch;        // [workspace_per_item][pitch]
 
@@ -127,10 +131,10 @@ __global__ __launch_bounds__(64) void trace_estimate_tile_kernel(const ff_trace_
     a.out[t] = trace::estimate<DC>(a.kind, it);
 }
 
-template <int DC>
+template <int DC, int ITEMS = 64>
 static hipError_t launch_tile(const ff_trace_args* a, long long items, size_t lds_bytes, hipStream_t s)
 {
-    auto kern = trace_estimate_tile_kernel<DC>;
+    auto kern = trace_estimate_tile_kernel<DC, ITEMS>;
     // the dynamic-LDS limit is a per-device attribute of the function: set it once per device of this process
     static std::atomic<unsigned char> ready[kMaxDevices];
     int dev = 0;
@@ -141,7 +145,7 @@ static hipError_t launch_tile(const ff_trace_args* a, long long items, size_t ld
         if (err != hipSuccess) return err;
         if (dev >= 0 && dev < kMaxDevices) ready[dev].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((items + 63) / 64)), dim3(64), lds_bytes, s, *a, items);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + ITEMS - 1) / ITEMS)), dim3(64), lds_bytes, s, *a, items);
     return hipGetLastError();
 }
 
@@ -169,11 +173,13 @@ extern "C" int ff_trace_estimate(const ff_trace_args* a, void* hip_stream)
     const long long items = (long long)a->n_rows * a->batch;
     if (items == 0) return FF_OK;
     hipStream_t s = (hipStream_t)hip_stream;
-    // the tile path: D <= 16 and a 64-item tile (matrices + scratch) within a CU's LDS (up to 80 KB two tiles
-    // share a CU and one loads while the other computes).  FF_TRACE_GENERIC=1 pins the general kernel (A/B runs, tests).
-    const size_t lds_bytes = 4 * ff::tile_lds_words(a->kind, a->dim, a->r);
+    // the tile path: the matrices and the scratch of a tile of work items within a CU's LDS -- 64 items up to 16 dimensions
+    // (up to 80 KB two tiles share a CU and one loads while the other computes), 32 items for 17-32 dimensions.
+    // FF_TRACE_GENERIC=1 pins the general kernel (A/B runs, tests).
     const char* pin = getenv("FF_TRACE_GENERIC");
-    if (a->dim <= 16 && lds_bytes <= 156 * 1024 && !(pin && atoi(pin) != 0) && (items + 63) / 64 <= 0x7fffffffll) {
+    const int tile_items = a->dim <= 16 ? 64 : 32;
+    const size_t lds_bytes = 4 * ff::tile_lds_words(a->kind, a->dim, a->r, tile_items);
+    if (a->dim <= 32 && lds_bytes <= 158 * 1024 && !(pin && atoi(pin) != 0) && (items + tile_items - 1) / tile_items <= 0x7fffffffll) {
         hipError_t err;
         switch (a->dim) {
         case 1: err = ff::launch_tile<1>(a, items, lds_bytes, s); break;
@@ -182,7 +188,10 @@ extern "C" int ff_trace_estimate(const ff_trace_args* a, void* hip_stream)
         case 4: err = ff::launch_tile<4>(a, items, lds_bytes, s); break;
         case 8: err = ff::launch_tile<8>(a, items, lds_bytes, s); break;
         case 16: err = ff::launch_tile<16>(a, items, lds_bytes, s); break;
-        default: err = ff::launch_tile<0>(a, items, lds_bytes, s); break;        // run-time dimension, same layout
+        case 32: err = ff::launch_tile<32, 32>(a, items, lds_bytes, s); break;
+        default:                                                                  // run-time dimension, same layout
+            err = a->dim <= 16 ? ff::launch_tile<0>(a, items, lds_bytes, s) : ff::launch_tile<0, 32>(a, items, lds_bytes, s);
+            break;
         }
         return err == hipSuccess ? FF_OK : FF_ERR_HIP;
     }

@@ -48,3 +48,20 @@ for pin in ("0", "1"):
         print(f"  ff_trace_estimate {kind} probes {tuple(probes[0].shape)}: {ms:.3f} ms for {gb:.2f} GB of Jacobians = "
               f"{gb / ms * 1e3:.0f} GB/s algorithmic (one read), {gb / ms * 1e3 / 8000:.3f} of the 8 TB/s HBM roofline", flush=True)
 os.environ.pop("FF_TRACE_GENERIC")
+# 32 dimensions (BASELINE config 5's state): tiles of 32 items
+B32 = 1 << 14
+jac = torch.randn(6, B32, 32, 32, device=dev)
+S32, G32 = (torch.sign(torch.randn(1, B32, 32, device=dev)) for _ in range(2))
+for pin in ("0", "1"):
+    os.environ["FF_TRACE_GENERIC"] = pin
+    _native.trace_estimate(jac, "hutchpp", (S32, G32))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        _native.trace_estimate(jac, "hutchpp", (S32, G32))
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    gb = jac.numel() * 4 / 1e9
+    print(f"32-d, r = m = 1, 6 x 2^14 items, {'LDS-tile kernel (32-item tiles)' if pin == '0' else 'general kernel'}: {ms:.3f} ms = "
+          f"{gb / ms * 1e3:.0f} GB/s algorithmic, {gb / ms * 1e3 / 8000:.3f} of the HBM roofline", flush=True)
+os.environ.pop("FF_TRACE_GENERIC")
