@@ -175,6 +175,7 @@ class NormTerm(ctypes.Structure):         # ff_norm_term
 NORM_TERMS = 3                      # FF_NORM_TERMS
 PRIOR_NOISE_INDEX = 0xFFFFFFFF     # FF_PRIOR_NOISE_INDEX
 PROBE_NOISE_INDEX = 0xFFFFFFFE     # FF_PROBE_NOISE_INDEX
+TRACE_PROBE_NOISE_BASE = 0xFFFE0000  # FF_TRACE_PROBE_NOISE_BASE (second probe set: + 0x8000)
 
 _lib = None
 

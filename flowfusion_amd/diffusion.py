@@ -631,8 +631,9 @@ class ScoreModel(nn.Module):
             return None
         if probe != "philox":
             raise ValueError(f"probe must be 'torch' or 'philox', not {probe!r}")
-        if not self.hutch:
-            raise ValueError("probe='philox' is the Hutchinson probe: construct the model with hutchinson=True")
+        if not (self.hutch or self.hutchpp or self.xtrace):
+            raise ValueError("probe='philox' draws the probes of a Hutchinson / Hutch++ / XTrace model: construct it with "
+                             "hutchinson=True, hutchpp=True or xtrace=True")
         if seed is None:      # one draw of torch's generator, so torch.manual_seed still fixes the run
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         return int(seed), int(sample_offset)
@@ -651,7 +652,9 @@ class ScoreModel(nn.Module):
             if in_shift is not None:
                 x0_samples = (x0_samples - in_shift) / in_scale
             if fused:
-                return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options)
+                return self._solve_with_estimator(x0_samples, conditional, atol, rtol, method, options, probe_rng)
+            if probe_rng is not None:
+                raise NotImplementedError("probe='philox' lives on the fused path; a custom score module draws its probes with torch")
             # any other module: forward() runs the estimator itself (reverse mode, like the reference); the probes are
             # drawn once per solve on the state's device (:703-719)
             (r, m), mx = self._probe_counts(x0_samples.shape[1])
@@ -682,7 +685,7 @@ class ScoreModel(nn.Module):
                                 in_shift=in_shift, in_scale=in_scale)
         return xT, dlogp.view(-1, 1)
 
-    def _solve_with_estimator(self, x0, conditional, atol, rtol, method, options):
+    def _solve_with_estimator(self, x0, conditional, atol, rtol, method, options, probe_rng=None):
         """Hutch++ / XTrace log-density solve.  The state never depends on the divergence, so the launches are those of the
         exact trace with the Jacobian of every evaluation row recorded (ff_ode_args.jac_all); the estimates of all rows
         come from ONE launch (ff_trace_estimate, csrc/ff_trace.hip) and are combined with the tableau's weights.  The
@@ -698,13 +701,17 @@ class ScoreModel(nn.Module):
                                f"(got a tensor on {x0.device}); there is no CPU fallback")
         B, D = x0.shape
         (r, m), mx = self._probe_counts(D)
+        if probe_rng is not None:       # probe="philox": keyed by (seed, global row), independent of the sharding
+            draw = lambda n, second=False: trace_estimators.draw_probes_philox(n, x0, probe_rng[0], probe_rng[1], second)
+        else:
+            draw = lambda n, second=False: trace_estimators.draw_probes(n, x0)
         if self.hutchpp:
-            self.S = trace_estimators.draw_probes(r, x0)
-            self.G = trace_estimators.draw_probes(m, x0)
+            self.S = draw(r)
+            self.G = draw(m, True)
             kind, probes = "hutchpp", (self.S, self.G)
         else:
             # the reference stores max(1, xt_vecs) probes and redraws inside forward when that exceeds D (:719, :409-416)
-            self.O = trace_estimators.draw_probes(mx, x0)
+            self.O = draw(mx)
             kind, probes = "xtrace", (self.O,)
         x = x0.detach().to(torch.float32).contiguous()
         t_span = torch.tensor([float(self.sde.epsilon), 1.0], dtype=torch.float32)

@@ -175,8 +175,8 @@ def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional:
     """``ScoreModel.log_prob`` of a [B, dim] batch over all ranks; one all-gather of the [B, 1] result at the end.
 
     ``x`` (and ``conditional``) are the full tensors, every rank slicing its rows -- or ``local_x`` (and
-    ``local_conditional``) are this rank's rows already, with ``n_total`` the size of the whole batch.  A Hutchinson
-    model takes its probe from the library's counter-based stream keyed by ``seed`` and the GLOBAL row
+    ``local_conditional``) are this rank's rows already, with ``n_total`` the size of the whole batch.  A Hutchinson,
+    Hutch++ or XTrace model takes its probes from the library's counter-based stream keyed by ``seed`` and the GLOBAL row
     (``probe="philox"``), so with a fixed-grid ``method`` a row's result does not depend on the number of ranks; the
     exact trace needs no random numbers.  ``**solver`` (atol, rtol, method, options) goes to ``log_prob`` unchanged.
     Under an adaptive ``method`` (the reference's default) the step size comes from the error norm of the WHOLE batch, as
@@ -203,7 +203,8 @@ def log_prob_sharded(score_model, x: Optional[torch.Tensor] = None, conditional:
             raise ValueError(f"rank {rank} of {world} owns rows [{lo}, {hi}) of {n}: local tensors must hold exactly those")
         rows = local_x.contiguous()
         cond = None if local_conditional is None else local_conditional.contiguous()
-    extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if getattr(score_model, "hutch", False) else {}
+    randomised = any(getattr(score_model, k, False) for k in ("hutch", "hutchpp", "xtrace"))
+    extra = {"probe": "philox", "seed": int(seed), "sample_offset": lo} if randomised else {}
     with _step_control(n, world, group, global_control, solver.get("method", "dopri5")):
         local = score_model.log_prob(rows, conditional=cond, **solver, **extra)
     if not gather:

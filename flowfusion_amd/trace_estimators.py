@@ -113,3 +113,16 @@ def draw_probes(n: int, like: torch.Tensor) -> torch.Tensor:
     (diffusion.py:708-719)."""
     B, D = like.shape
     return torch.sign(torch.randn(n, B, D, device=like.device, dtype=like.dtype))
+
+
+def draw_probes_philox(n: int, like: torch.Tensor, seed: int, sample_offset: int, second_set: bool = False) -> torch.Tensor:
+    """[n, B, D] +-1 probes from the library's counter-based stream (``ff_normal_fill`` with the reserved indices
+    FF_TRACE_PROBE_NOISE_BASE + c): probe c of global row ``sample_offset + r`` is the sign of that row's normal -- drawn on
+    the device and independent of how a batch is cut into shards.  ``second_set`` = the residual probes G of Hutch++."""
+    from . import _native
+    B, D = like.shape
+    base = _native.TRACE_PROBE_NOISE_BASE + (0x8000 if second_set else 0)
+    if n > 0x8000:
+        raise ValueError("at most 32768 probes per set")
+    zs = [_native.normal_fill(B, D, seed, sample_offset, like.device, noise_index=base + c) for c in range(n)]
+    return torch.where(torch.stack(zs) >= 0, 1.0, -1.0).to(torch.float32)

@@ -283,6 +283,11 @@ int ff_last_hip_error(void);
  * host draw `torch.sign(torch.randn(shape)).to(device)` (diffusion.py:701) when a log-density batch is sharded over GPUs
  * or the host draw should leave the critical path (host side: probe="philox"). */
 #define FF_PROBE_NOISE_INDEX 0xFFFFFFFEu
+/* Noise indices reserved for the Hutch++ / XTrace probes of a sample (diffusion.py:703-719: S, G, O drawn once per solve as
+ * `torch.sign(torch.randn(n, B, D))`): probe c of the FIRST set (S, or O) is the sign of z(seed, global row,
+ * FF_TRACE_PROBE_NOISE_BASE + c, d), probe c of the SECOND set (G) that of index FF_TRACE_PROBE_NOISE_BASE + 0x8000 + c
+ * (host side: probe="philox" on a model with hutchpp=True / xtrace=True) -- the same probes whatever the sharding. */
+#define FF_TRACE_PROBE_NOISE_BASE 0xFFFE0000u
 
 /*
  * out[r][d] = scale * z(seed, global row sample_offset + r, noise_index, d)  for r < batch, d < dim, with z the

@@ -187,3 +187,41 @@ def test_estimator_solves_at_size_properties(monkeypatch):
             assert torch.equal(a, b) and torch.isfinite(a).all() and sm.last_solver_stats["chunks"] <= 2
             assert torch.equal(run(-1.0), a)
     sm.hutchpp = sm.xtrace = False
+
+
+def test_estimator_probes_from_the_counter_based_stream():
+    """probe="philox" on a Hutch++ / XTrace model: S, G, O are the signs of the library's counter-based normals keyed by
+    (seed, global row, a reserved index per probe) -- drawn on the device, the same whatever the sharding: a slice of the
+    batch solved on its own returns the rows of the whole solve bit for bit (what distributed.log_prob_sharded relies on),
+    and the signs equal the numpy restatement of the stream."""
+    import numpy as np
+    from flowfusion_amd import _native
+    from flowfusion_amd.distributed import log_prob_sharded
+    from tests._philox import normals
+    sm, _, _ = _seeded_score_model(8, 2, [128, 128], "VPSDE", True, 44)
+    torch.manual_seed(2)
+    B = 400
+    x, cond = torch.randn(B, 8, device=DEV) * 0.6, torch.randn(B, 2, device=DEV)
+    opts = {"step_size": (1.0 - float(sm.sde.epsilon)) / 6}
+    lo, hi = 130, 333
+    for kind in ("hutchpp", "xtrace"):
+        sm.hutchpp, sm.xtrace, sm.hpp_rank, sm.hpp_vector, sm.xt_vector = kind == "hutchpp", kind == "xtrace", 2, 3, 2
+        kw = dict(conditional=cond, method="rk4", options=opts, probe="philox")
+        lp = sm.log_prob(x, seed=71, **kw)
+        first = sm.S if kind == "hutchpp" else sm.O
+        z = normals(71, 0, B, 8, [_native.TRACE_PROBE_NOISE_BASE, _native.TRACE_PROBE_NOISE_BASE + 1])
+        far = np.abs(z) > 1e-5
+        assert np.array_equal(first.cpu().numpy()[far], np.where(z >= 0, 1.0, -1.0)[far]) and far.mean() > 0.999
+        if kind == "hutchpp":
+            zg = normals(71, 0, B, 8, [_native.TRACE_PROBE_NOISE_BASE + 0x8000 + c for c in range(3)])
+            farg = np.abs(zg) > 1e-5
+            assert np.array_equal(sm.G.cpu().numpy()[farg], np.where(zg >= 0, 1.0, -1.0)[farg])
+        ok = torch.isfinite(lp).reshape(-1)
+        assert ok.float().mean() > 0.97                                 # (two equal probes of a sample: ill-posed, as in the reference)
+        assert torch.equal(sm.log_prob(x, seed=71, **kw)[ok], lp[ok]) and not torch.equal(sm.log_prob(x, seed=72, **kw)[ok], lp[ok])
+        part = sm.log_prob(x[lo:hi].contiguous(), seed=71, sample_offset=lo, **{**kw, "conditional": cond[lo:hi].contiguous()})
+        assert torch.equal(part[ok[lo:hi]], lp[lo:hi][ok[lo:hi]])
+        assert torch.equal(log_prob_sharded(sm, x, cond, seed=71, method="rk4", options=opts)[ok], lp[ok])
+    sm.hutchpp = sm.xtrace = False
+    with pytest.raises(ValueError, match="hutchinson=True, hutchpp=True or xtrace=True"):
+        sm.log_prob(x, conditional=cond, probe="philox")
