@@ -7,4 +7,4 @@
 from . import diffusion, flow  # noqa: F401
 
 __all__ = ["diffusion", "flow"]
-__version__ = "0.1.0"
+__version__ = "0.4.0"
