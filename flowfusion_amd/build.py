@@ -132,12 +132,14 @@ else:
 # A handful of instantiations compiled with -DFF_DEBUG_SKEW (one wavefront of every workgroup held back where a missing
 # barrier would show) beside the product library, never in it:
 #   skew        HEAD's kernels: the 256-wide cooperative twin (state-only and with tangent columns) and its one-wavefront
-#               kernel, the wide catch-all, one split-precision kernel
+#               kernel, the wide catch-all's code path instantiated at width 256 (a tenth of the 1024-wide unit's compile
+#               time; the product serves that shape with a one-wavefront kernel, which gives the test its reference), one
+#               split-precision kernel
 #   skew_unfix  the same twin with round 3's two synchronisation fixes removed again (-DFF_DEBUG_UNFIX): what the test must
 #               see FAIL, or it guards nothing
 _SKEW_TWIN = [(16, 256, 4, 0, t, 2, 8, 0) for t in (0, 1)]
 VARIANTS = {
-    "skew": dict(defines=["-DFF_DEBUG_SKEW=0"], instances=_SKEW_TWIN, wide=[(16, 1024, 32, 16, 0)], split=[(3, 0, 2, 1, 128)]),
+    "skew": dict(defines=["-DFF_DEBUG_SKEW=0"], instances=_SKEW_TWIN, wide=[(16, 256, 8, 4, 0)], split=[(3, 0, 2, 1, 128)]),
     "skew_unfix": dict(defines=["-DFF_DEBUG_SKEW=0", "-DFF_DEBUG_UNFIX=1"], instances=_SKEW_TWIN, wide=[], split=[]),
 }
 

@@ -160,18 +160,21 @@ def test_unfixed_twin_fails_under_skew_and_head_does_not(libs):
 def test_wide_catch_all_and_split_kernel_under_skew(libs):
     """The other kernels that share LDS across wavefronts, held back the same way: bitwise their un-skewed product builds."""
     torch.manual_seed(6)
-    # WIDE: one exchange buffer, two barriers per layer, operands read from LDS during the next layer
-    sw, _, _ = _seeded_score_model(20, 0, [600, 600, 600], "VESDE", False, 23)
-    assert "wide" in _native.kernel_name(sw._net().plan(0))
+    # WIDE: one exchange buffer, two barriers per layer, operands read from LDS during the next layer.  The skew library
+    # holds the wide kernel at width 256 / 32 dimensions; the product serves that shape with a ONE-WAVEFRONT kernel (same packed
+    # layout, same FMA chains): the skewed wide kernel must reproduce it bit for bit.
+    sw, _, _ = _seeded_score_model(20, 0, [200, 256, 256], "VESDE", False, 23)
+    assert "wide" not in _native.kernel_name(sw._net().plan(0))
+    assert b"wide" in libs["skew"].ff_plan_kernel_name(ctypes.byref(_plan(libs["skew"], sw._net(), 0)))
     x = torch.randn(70, 20, device=DEV)
     t_span = torch.tensor([1.0, float(sw.sde.epsilon)])
     tab = sw._ode_table(t_span, "rk4", {"step_size": 0.34}, 0).to(DEV)
     k1 = torch.randn(70, 20, device=DEV)
-    ref = _launch(libs["product"], sw, 0, x, tab, tab.shape[0])
+    ref = _launch(libs["product"], sw, 0, x, tab, tab.shape[0], coop=False)
     got = _launch(libs["skew"], sw, 0, x, tab, tab.shape[0])
     assert torch.equal(got[0], ref[0]) and torch.isfinite(ref[0]).all()
     att = _attempt_table(sw, 4, 0, DEV)
-    ref = _launch(libs["product"], sw, 0, x, att, 4, k1=k1, n_aux=1)
+    ref = _launch(libs["product"], sw, 0, x, att, 4, k1=k1, n_aux=1, coop=False)
     got = _launch(libs["skew"], sw, 0, x, att, 4, k1=k1, n_aux=1)
     assert torch.equal(got[1], ref[1])
     # split precision (bf16x2, three hidden layers of 128): a ring of weight granules, one barrier per granule
